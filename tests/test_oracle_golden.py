@@ -1,0 +1,84 @@
+"""The CPU oracle against the golden vectors recorded from the unmodified reference.
+
+tests/golden/* were produced by tests/golden/make_golden.py from the reference compiled by
+oracle/Makefile, run one process per read (isolated semantics).  Every capture point (G1 ranges,
+G3 wrap-around DP calls, G3p polish, G3r revision, G4 inserted records) and the final stdout (G5)
+must match byte for byte, for the default (Manhattan), -p (Pearson) and -a (alignment) modes.
+"""
+import glob
+import gzip
+import hashlib
+import json
+import os
+import subprocess
+import tempfile
+
+import pytest
+
+from tests.conftest import GOLDEN
+
+FLAGS = {"default": [], "p": ["-p"], "a": ["-a"]}
+
+
+def _cases():
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLDEN, "*.stdout"))):
+        name, mode, _ = os.path.basename(p).rsplit(".", 2)
+        out.append((name, mode))
+    return out
+
+
+def _input(name):
+    for ext in (".fa", ".fasta"):
+        p = os.path.join(GOLDEN, "inputs", name + ext)
+        if os.path.exists(p):
+            return p
+    raise FileNotFoundError(name)
+
+
+@pytest.mark.parametrize("name,mode", _cases())
+def test_oracle_matches_reference_golden(oracle_cli, name, mode):
+    with tempfile.NamedTemporaryFile(suffix=".jsonl") as cap:
+        p = subprocess.run([oracle_cli, *FLAGS[mode], "-l", "1", "-C", cap.name, _input(name)], capture_output=True, check=True)
+        got_cap = open(cap.name, "rb").read()
+    want = open(os.path.join(GOLDEN, f"{name}.{mode}.stdout"), "rb").read()
+    assert p.stdout == want, f"stdout (G5) differs for {name} [{mode}]"
+    cap_path = os.path.join(GOLDEN, f"{name}.{mode}.cap.jsonl.gz")
+    if os.path.exists(cap_path):
+        want_cap = gzip.open(cap_path, "rb").read()
+        if got_cap != want_cap:
+            g, w = got_cap.split(b"\n"), want_cap.split(b"\n")
+            for i, (x, y) in enumerate(zip(g, w)):
+                assert x == y, f"capture line {i} differs for {name} [{mode}]:\n got  {x[:200]!r}\n want {y[:200]!r}"
+            assert len(g) == len(w)
+
+
+def test_manifest_is_consistent():
+    man = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
+    for rel, digest in man["files"].items():
+        p = os.path.join(GOLDEN, rel)
+        data = gzip.open(p, "rb").read() if p.endswith(".gz") else open(p, "rb").read()
+        assert hashlib.md5(data).hexdigest() == digest, rel
+
+
+# md5 of the reference's stdout on its own bundled single-read files
+APPENDIX_C = {
+    ("3_5", "default"): "5b17b00a36c809f28b4aeb9d4a6199b3", ("3_5", "p"): "3e4b2f90d3aa4e8f8b1bc49d551eff42",
+    ("3_5", "a"): "f66b67047bce58c95495eaa134edc88d", ("10_50", "default"): "b4ed5ed2b3bf06b8f0e5296e174c5381",
+    ("10_50", "p"): "6e28d7cd0bd30975ecfc5e149c6b1efa", ("10_50", "a"): "0ee9584f80fe373c771cc3cac719654f",
+    ("2_5_10_20_set", "default"): "9bdd2886b2ab2c13234e1b8e580f6b49", ("20_50", "a"): "561f1732f894bb1343f57e1aa793fa5e",
+    ("5_20", "p"): "ead507e994e862be4a711172f7ea5ed6", ("3_50", "default"): "cc7cae93b0fb6ff07bdc2896510fd7b6",
+}
+
+
+@pytest.mark.parametrize("key", sorted(APPENDIX_C))
+def test_known_answer_fingerprints(oracle_cli, key):
+    name, mode = key
+    p = subprocess.run([oracle_cli, *FLAGS[mode], _input(name)], capture_output=True, check=True)
+    assert hashlib.md5(p.stdout).hexdigest() == APPENDIX_C[key]
+
+
+def test_smallest_literal_known_answer(oracle_cli):
+    p = subprocess.run([oracle_cli, _input("3_5")], capture_output=True, check=True)
+    assert p.stdout.decode() == ("0\t2618\t1004\t1139\t136\t3\t46\t112\t0.823529\t22\t2\t4\tGCT\n"
+                                 "0\t2618\t1144\t1615\t472\t5\t98\t403\t0.853814\t57\t12\t33\tGCTAG\n")

@@ -1,0 +1,134 @@
+/*
+ * mtr_hip.h — C-ABI of libmtr_hip.so, the MI355X (gfx950) implementation of reference mTR's
+ * per-read hot path.
+ *
+ * The reference has no FFI; the seam this library stands behind is the function boundary of its
+ * per-read layer:
+ *
+ *   upper edge  void handle_one_read(char *readID, int inputLen, int read_cnt, int print_alignment)
+ *               (reference mTR.h:127, called from handle_one_file.c:286), whose inputs also arrive
+ *               through the globals orgInputString (mTR.h:65), Manhattan_Distance (mTR.h:61, -p sets
+ *               it to 0) and min_match_ratio (mTR.h:62, -m);
+ *   lower edge  insert_an_alignment_into_set(...17 arguments...) (mTR.h:151-168), called once per
+ *               qualified repeat in candidate order (handle_one_read.c:156-176, :239-243).
+ *
+ * mtr_process_batch() is the batch form of that edge: it takes N reads as integer base codes
+ * (what handle_one_file.c:284-285 copies into orgInputString) and returns, per read and in the
+ * reference's insertion order, exactly the 17 arguments of insert_an_alignment_into_set (readID and
+ * inputLen are the caller's own).  Chaining + printing (chaining.cpp) stay on the host side of the
+ * boundary (mtr_amd/host/).
+ *
+ * Semantics = the reference run one read per process ("isolated semantics"): the
+ * results do not depend on which other reads share the batch.
+ *
+ * Conventions: every entry point returns an mtr_status; nothing calls exit(); the context owns all
+ * device memory; one context per GPU / host thread; not re-entrant on one context.
+ * There is NO CPU fallback: without a HIP device every entry point fails with MTR_ERR_NO_DEVICE.
+ */
+#ifndef MTR_HIP_H
+#define MTR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTR_MAX_PERIOD 500          /* reference mTR.h:35 MAX_PERIOD */
+#define MTR_MAX_INPUT_LENGTH 1000000 /* reference mTR.h:31 */
+#define MTR_ABI_VERSION 1
+
+typedef enum {
+    MTR_OK = 0,
+    MTR_ERR_NO_DEVICE = 1,      /* no HIP device / HIP runtime error at create */
+    MTR_ERR_BAD_ARG = 2,        /* null pointer, bad length (<=0 or > MTR_MAX_INPUT_LENGTH), bad code (>3) */
+    MTR_ERR_OOM = 3,            /* host or device allocation failed */
+    MTR_ERR_HIP = 4,            /* a HIP call failed; mtr_last_error() has the text */
+    MTR_ERR_OVERFLOW = 5,       /* a per-read result buffer overflowed (raise MTR_MAX_RECORDS_PER_READ) */
+    MTR_ERR_DP_TOO_LARGE = 6    /* a DP exceeded the reference's WrapDPsize (mTR.h:51): the reference exits */
+} mtr_status;
+
+/* One qualified repeat = arguments 3..17 of insert_an_alignment_into_set (mTR.h:151-168). */
+typedef struct mtr_record {
+    int32_t rep_start;          /* 0-origin, inclusive */
+    int32_t rep_end;            /* 0-origin, inclusive */
+    int32_t repeat_len;
+    int32_t rep_period;
+    int32_t num_freq_unit;
+    int32_t num_matches;
+    int32_t num_mismatches;
+    int32_t num_insertions;
+    int32_t num_deletions;
+    int32_t kmer;
+    int32_t match_gain;
+    int32_t mismatch_penalty;
+    int32_t indel_penalty;
+    int32_t reserved;
+    char    unit[MTR_MAX_PERIOD + 4];        /* "string", NUL-terminated ACGT */
+    int32_t unit_score[MTR_MAX_PERIOD];      /* "string_score", first rep_period entries valid */
+} mtr_record;
+
+typedef struct mtr_ctx mtr_ctx;
+
+/* device: HIP device ordinal.  manhattan: 1 = Manhattan DI (default), 0 = Pearson (-p).
+ * min_match_ratio: the -m value (reference default 0.6, MIN_MATCH_RATIO mTR.h:32). */
+mtr_status mtr_create(int device, int manhattan, float min_match_ratio, mtr_ctx **out);
+void       mtr_destroy(mtr_ctx *ctx);
+const char *mtr_last_error(const mtr_ctx *ctx);
+int        mtr_abi_version(void);
+
+/* Replaces the per-read loop body of handle_one_file.c:281-287 for n_reads reads at once.
+ *   bases    concatenated base codes, one byte per base, 0..3 = A C G T (handle_one_file.c:169-188)
+ *   offsets  n_reads start offsets into bases
+ *   lens     n_reads lengths (1..MTR_MAX_INPUT_LENGTH)
+ * On success *out_records is a malloc'ed array of all records, read after read, each read's records
+ * in insertion order; (*out_counts)[i] is the number of records of read i.  Free both with
+ * mtr_free_results(). */
+mtr_status mtr_process_batch(mtr_ctx *ctx, const uint8_t *bases, const int64_t *offsets, const int32_t *lens,
+                             int32_t n_reads, mtr_record **out_records, int32_t **out_counts, int64_t *out_total);
+void       mtr_free_results(mtr_record *records, int32_t *counts);
+
+/* The same path split so that a caller (bench.py) can keep inputs resident in HBM and time only the
+ * device work: upload packs the reads to 2 bit/base and copies them to the device; run launches the
+ * kernels on the context's stream and returns after they finish; fetch copies the records back. */
+mtr_status mtr_upload_batch(mtr_ctx *ctx, const uint8_t *bases, const int64_t *offsets, const int32_t *lens, int32_t n_reads);
+mtr_status mtr_run_resident(mtr_ctx *ctx);
+mtr_status mtr_fetch_results(mtr_ctx *ctx, mtr_record **out_records, int32_t **out_counts, int64_t *out_total);
+
+/* Per-kernel device time of the last mtr_run_resident()/mtr_process_batch(), measured with HIP events
+ * on the stream the kernels were launched on.  Kernel ids: 0 = ranges (K1), 1 = units+DP (K2). */
+typedef struct mtr_kernel_time { float ms; int32_t launches; } mtr_kernel_time;
+mtr_status mtr_get_kernel_times(const mtr_ctx *ctx, mtr_kernel_time *out, int32_t n_kernels);
+
+/* Work counters of the last run, accumulated on the device (used for the roofline figures):
+ * [0] wrap-around DP calls, [1] DP cells, [2] DP rows, [3] revision DP calls, [4] revision DP cells,
+ * [5] k-mer tables built, [6] k-mer look-ups, [7] candidate ranges, [8] ranges executed, [9] records,
+ * [10] DI passes, [11] DI positions, [12] traceback steps, [13] undefined-behaviour guards hit. */
+#define MTR_N_COUNTERS 16
+mtr_status mtr_get_counters(const mtr_ctx *ctx, int64_t *out, int32_t n);
+
+/* ---- building blocks, exported for parity tests (same kernels the batch path runs) ------------- */
+
+/* K1 alone = fill_directional_index_with_end (fill_directional_index.c:549-602) for every read of the
+ * uploaded batch.  Returns per read the surviving candidate ranges (start ascending): start, end, w
+ * and the DI value's IEEE-754 bit pattern.  Arrays are malloc'ed; free() them. */
+mtr_status mtr_test_ranges(mtr_ctx *ctx, int32_t **out_counts, int32_t **out_start, int32_t **out_end,
+                           int32_t **out_w, uint64_t **out_di_bits, int64_t *out_total);
+
+/* wrap_around_DP_sub (wrap_around_DP.c:222-354) for n_tasks (read, window, unit, scores) tasks on the
+ * uploaded batch.  unit codes 0..3, units concatenated, unit_off[n_tasks+1].  out8[8*t..] =
+ * rep_start, rep_end, repeat_len, Num_freq_unit, matches, mismatches, insertions, deletions. */
+mtr_status mtr_test_wrap_dp(mtr_ctx *ctx, int32_t n_tasks, const int32_t *read_idx, const int32_t *query_start,
+                            const int32_t *query_end, const uint8_t *units, const int32_t *unit_off,
+                            const int32_t *gain, const int32_t *mismatch, const int32_t *indel, int32_t *out8);
+
+/* Event trace of the last run (debug aid for parity work): enable before mtr_run_resident.
+ * Each event is 16 int32: [0]=type (2 search, 3 DP, 4 polish, 5 revise, 6 record), [1]=read index,
+ * then type-specific fields (see mtr_amd/csrc/mtr_device.hip). */
+mtr_status mtr_set_trace(mtr_ctx *ctx, int32_t max_events);
+mtr_status mtr_get_trace(mtr_ctx *ctx, int32_t **out_events, int64_t *out_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTR_HIP_H */

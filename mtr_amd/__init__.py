@@ -1,0 +1,261 @@
+"""mtr_amd — MI355X (gfx950) implementation of reference mTR's per-read hot path.
+
+Python host-side mirror of the C-ABI in include/mtr_hip.h (ctypes; plain pointers, no torch types).
+The product path is libmtr_hip.so only: importing works without a GPU, but creating an Engine
+without the library or without a HIP device raises — there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, NamedTuple, Sequence
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmtr_hip.so")
+MAX_PERIOD = 500
+
+STATUS = {0: "MTR_OK", 1: "MTR_ERR_NO_DEVICE", 2: "MTR_ERR_BAD_ARG", 3: "MTR_ERR_OOM", 4: "MTR_ERR_HIP",
+          5: "MTR_ERR_OVERFLOW", 6: "MTR_ERR_DP_TOO_LARGE"}
+COUNTER_NAMES = ["dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_dp_cells", "kmer_tables", "kmer_lookups",
+                 "ranges_candidate", "ranges_executed", "records", "di_passes", "di_positions", "traceback_steps",
+                 "undefined_guards", "global_tables", "reserved"]
+EXPORTS = ["mtr_create", "mtr_destroy", "mtr_last_error", "mtr_abi_version", "mtr_process_batch", "mtr_free_results",
+           "mtr_upload_batch", "mtr_run_resident", "mtr_fetch_results", "mtr_get_kernel_times", "mtr_get_counters",
+           "mtr_test_ranges", "mtr_test_wrap_dp", "mtr_set_trace", "mtr_get_trace"]
+
+
+class MtrError(RuntimeError):
+    pass
+
+
+class CRecord(C.Structure):
+    _fields_ = [("rep_start", C.c_int32), ("rep_end", C.c_int32), ("repeat_len", C.c_int32), ("rep_period", C.c_int32),
+                ("num_freq_unit", C.c_int32), ("num_matches", C.c_int32), ("num_mismatches", C.c_int32),
+                ("num_insertions", C.c_int32), ("num_deletions", C.c_int32), ("kmer", C.c_int32), ("match_gain", C.c_int32),
+                ("mismatch_penalty", C.c_int32), ("indel_penalty", C.c_int32), ("reserved", C.c_int32),
+                ("unit", C.c_char * (MAX_PERIOD + 4)), ("unit_score", C.c_int32 * MAX_PERIOD)]
+
+
+class CKernelTime(C.Structure):
+    _fields_ = [("ms", C.c_float), ("launches", C.c_int32)]
+
+
+class Record(NamedTuple):
+    """The 15 per-repeat arguments of insert_an_alignment_into_set (reference mTR.h:151-168)."""
+    rep_start: int
+    rep_end: int
+    repeat_len: int
+    rep_period: int
+    num_freq_unit: int
+    num_matches: int
+    num_mismatches: int
+    num_insertions: int
+    num_deletions: int
+    kmer: int
+    match_gain: int
+    mismatch_penalty: int
+    indel_penalty: int
+    unit: str
+    unit_score: tuple
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen libmtr_hip.so; raises if it has not been built (python -m mtr_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise MtrError(f"{path} is missing: build it with `python -m mtr_amd.build` (hipcc, gfx950); there is no CPU fallback")
+    lib = C.CDLL(path)
+    P = C.POINTER
+    lib.mtr_create.argtypes = [C.c_int, C.c_int, C.c_float, P(C.c_void_p)]
+    lib.mtr_create.restype = C.c_int
+    lib.mtr_destroy.argtypes = [C.c_void_p]
+    lib.mtr_destroy.restype = None
+    lib.mtr_last_error.argtypes = [C.c_void_p]
+    lib.mtr_last_error.restype = C.c_char_p
+    lib.mtr_abi_version.restype = C.c_int
+    lib.mtr_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, P(P(CRecord)), P(P(C.c_int32)), P(C.c_int64)]
+    lib.mtr_process_batch.restype = C.c_int
+    lib.mtr_free_results.argtypes = [C.c_void_p, C.c_void_p]
+    lib.mtr_free_results.restype = None
+    lib.mtr_upload_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.mtr_upload_batch.restype = C.c_int
+    lib.mtr_run_resident.argtypes = [C.c_void_p]
+    lib.mtr_run_resident.restype = C.c_int
+    lib.mtr_fetch_results.argtypes = [C.c_void_p, P(P(CRecord)), P(P(C.c_int32)), P(C.c_int64)]
+    lib.mtr_fetch_results.restype = C.c_int
+    lib.mtr_get_kernel_times.argtypes = [C.c_void_p, P(CKernelTime), C.c_int32]
+    lib.mtr_get_kernel_times.restype = C.c_int
+    lib.mtr_get_counters.argtypes = [C.c_void_p, P(C.c_int64), C.c_int32]
+    lib.mtr_get_counters.restype = C.c_int
+    lib.mtr_test_ranges.argtypes = [C.c_void_p, P(P(C.c_int32)), P(P(C.c_int32)), P(P(C.c_int32)), P(P(C.c_int32)), P(P(C.c_uint64)), P(C.c_int64)]
+    lib.mtr_test_ranges.restype = C.c_int
+    lib.mtr_test_wrap_dp.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 9
+    lib.mtr_test_wrap_dp.restype = C.c_int
+    lib.mtr_set_trace.argtypes = [C.c_void_p, C.c_int32]
+    lib.mtr_set_trace.restype = C.c_int
+    lib.mtr_get_trace.argtypes = [C.c_void_p, P(P(C.c_int32)), P(C.c_int64)]
+    lib.mtr_get_trace.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def _flatten(reads: Sequence[np.ndarray]):
+    lens = np.array([len(r) for r in reads], dtype=np.int32)
+    offs = np.zeros(len(reads), dtype=np.int64)
+    if len(reads) > 1:
+        offs[1:] = np.cumsum(lens[:-1], dtype=np.int64)
+    bases = np.concatenate([np.asarray(r, dtype=np.uint8) for r in reads]) if len(reads) else np.zeros(0, np.uint8)
+    return np.ascontiguousarray(bases), offs, lens
+
+
+class Engine:
+    """One context per GPU (mtr_create).  manhattan=False is the reference's -p; min_match_ratio its -m."""
+
+    def __init__(self, device: int = 0, manhattan: bool = True, min_match_ratio: float = 0.6):
+        self.lib = load_library()
+        h = C.c_void_p()
+        st = self.lib.mtr_create(device, 1 if manhattan else 0, C.c_float(min_match_ratio), C.byref(h))
+        if st != 0:
+            raise MtrError(f"mtr_create failed: {STATUS.get(st, st)} (a HIP device is required; there is no CPU fallback)")
+        self.h = h
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mtr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st: int, what: str):
+        if st != 0:
+            raise MtrError(f"{what}: {STATUS.get(st, st)}: {self.lib.mtr_last_error(self.h).decode(errors='replace')}")
+
+    # ---- the batch edge -------------------------------------------------------------------------------
+    def upload(self, reads: Sequence[np.ndarray]):
+        bases, offs, lens = _flatten(reads)
+        self._keep = (bases, offs, lens)
+        self._check(self.lib.mtr_upload_batch(self.h, bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(reads)), "mtr_upload_batch")
+        self.n_reads = len(reads)
+
+    def run(self):
+        self._check(self.lib.mtr_run_resident(self.h), "mtr_run_resident")
+
+    def fetch(self) -> List[List[Record]]:
+        recs = C.POINTER(CRecord)()
+        cnts = C.POINTER(C.c_int32)()
+        total = C.c_int64()
+        self._check(self.lib.mtr_fetch_results(self.h, C.byref(recs), C.byref(cnts), C.byref(total)), "mtr_fetch_results")
+        try:
+            return self._unpack(recs, cnts, self.n_reads)
+        finally:
+            self.lib.mtr_free_results(recs, cnts)
+
+    def process(self, reads: Sequence[np.ndarray]) -> List[List[Record]]:
+        """mtr_process_batch: reads = sequences of base codes 0..3; returns per read its records in insertion order."""
+        bases, offs, lens = _flatten(reads)
+        recs = C.POINTER(CRecord)()
+        cnts = C.POINTER(C.c_int32)()
+        total = C.c_int64()
+        self._check(self.lib.mtr_process_batch(self.h, bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(reads),
+                                               C.byref(recs), C.byref(cnts), C.byref(total)), "mtr_process_batch")
+        self.n_reads = len(reads)
+        try:
+            return self._unpack(recs, cnts, len(reads))
+        finally:
+            self.lib.mtr_free_results(recs, cnts)
+
+    @staticmethod
+    def _unpack(recs, cnts, n) -> List[List[Record]]:
+        out, p = [], 0
+        for i in range(n):
+            lst = []
+            for _ in range(cnts[i]):
+                r = recs[p]
+                p += 1
+                per = r.rep_period
+                lst.append(Record(r.rep_start, r.rep_end, r.repeat_len, per, r.num_freq_unit, r.num_matches, r.num_mismatches,
+                                  r.num_insertions, r.num_deletions, r.kmer, r.match_gain, r.mismatch_penalty, r.indel_penalty,
+                                  r.unit.decode(), tuple(r.unit_score[:max(0, min(per, MAX_PERIOD))])))
+            out.append(lst)
+        return out
+
+    # ---- measurements ------------------------------------------------------------------------------------
+    def kernel_times_ms(self):
+        kt = (CKernelTime * 2)()
+        self._check(self.lib.mtr_get_kernel_times(self.h, kt, 2), "mtr_get_kernel_times")
+        return {"k1_ranges": float(kt[0].ms), "k2_units": float(kt[1].ms)}
+
+    def counters(self):
+        c = (C.c_int64 * 16)()
+        self._check(self.lib.mtr_get_counters(self.h, c, 16), "mtr_get_counters")
+        return {n: int(c[i]) for i, n in enumerate(COUNTER_NAMES)}
+
+    # ---- building blocks (parity tests) ----------------------------------------------------------------------
+    def test_ranges(self):
+        """K1 alone on the uploaded batch -> per read list of (start, end, w, di_bits)."""
+        P = C.POINTER
+        pc, ps, pe, pw, pd, tot = P(C.c_int32)(), P(C.c_int32)(), P(C.c_int32)(), P(C.c_int32)(), P(C.c_uint64)(), C.c_int64()
+        self._check(self.lib.mtr_test_ranges(self.h, C.byref(pc), C.byref(ps), C.byref(pe), C.byref(pw), C.byref(pd), C.byref(tot)), "mtr_test_ranges")
+        out, p = [], 0
+        for i in range(self.n_reads):
+            out.append([(ps[p + t], pe[p + t], pw[p + t], pd[p + t]) for t in range(pc[i])])
+            p += pc[i]
+        for ptr in (pc, ps, pe, pw, pd):
+            _libc.free(C.cast(ptr, C.c_void_p))
+        return out
+
+    def test_wrap_dp(self, tasks):
+        """tasks: list of (read_idx, qs, qe, unit codes, G, MM, D) -> int32 [n,8] as wrap_around_DP_sub returns."""
+        n = len(tasks)
+        rd = np.array([t[0] for t in tasks], np.int32)
+        qs = np.array([t[1] for t in tasks], np.int32)
+        qe = np.array([t[2] for t in tasks], np.int32)
+        uo = np.zeros(n + 1, np.int32)
+        uo[1:] = np.cumsum([len(t[3]) for t in tasks])
+        units = np.ascontiguousarray(np.concatenate([np.asarray(t[3], np.uint8) for t in tasks]))
+        g = np.array([t[4] for t in tasks], np.int32)
+        m = np.array([t[5] for t in tasks], np.int32)
+        d = np.array([t[6] for t in tasks], np.int32)
+        out = np.zeros((n, 8), np.int32)
+        self._check(self.lib.mtr_test_wrap_dp(self.h, n, rd.ctypes.data, qs.ctypes.data, qe.ctypes.data, units.ctypes.data, uo.ctypes.data,
+                                              g.ctypes.data, m.ctypes.data, d.ctypes.data, out.ctypes.data), "mtr_test_wrap_dp")
+        return out
+
+    def set_trace(self, max_events: int):
+        self._check(self.lib.mtr_set_trace(self.h, max_events), "mtr_set_trace")
+
+    def get_trace(self) -> np.ndarray:
+        ev = C.POINTER(C.c_int32)()
+        n = C.c_int64()
+        self._check(self.lib.mtr_get_trace(self.h, C.byref(ev), C.byref(n)), "mtr_get_trace")
+        arr = np.ctypeslib.as_array(ev, shape=(max(n.value, 1), 16))[: n.value].copy()
+        _libc.free(C.cast(ev, C.c_void_p))
+        return arr
+
+
+def codes_from_str(s: str) -> np.ndarray:
+    """ACGT/acgt -> 0..3 (reference handle_one_file.c:169-188); anything else raises like the reference exits."""
+    lut = np.full(256, 255, np.uint8)
+    for ch, v in zip("ACGTacgt", [0, 1, 2, 3, 0, 1, 2, 3]):
+        lut[ord(ch)] = v
+    a = lut[np.frombuffer(s.encode(), np.uint8)]
+    if (a == 255).any():
+        bad = s[int(np.argmax(a == 255))]
+        raise ValueError(f"Invalid character: {bad}")
+    return a

@@ -1,0 +1,46 @@
+"""Build libmtr_hip.so (hand-written HIP for gfx950) in-tree with hipcc.  No fallback: if hipcc is
+missing or the build fails this raises."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmtr_hip.so")
+SOURCES = ["mtr_abi.hip", "mtr_common.h", "device_util.hip.inc", "k1_ranges.hip.inc", "k2_units.hip.inc",
+           "dp_wrap.hip.inc", "min_missing_table.h", os.path.join("..", "..", "include", "mtr_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+         "-ffp-contract=off", "-fno-fast-math",      # fp64 DI values and float ratios must round exactly like the reference's C
+         "-fhip-fp32-correctly-rounded-divide-sqrt"]
+
+
+def hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libmtr_hip.so cannot be built (there is no CPU fallback)")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc(), *FLAGS, "-o", LIB, os.path.join(CSRC, "mtr_abi.hip")]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+    if p.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + p.stdout + p.stderr)
+    if verbose:
+        print(" ".join(cmd))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,456 @@
+// mtr_abi.hip — host side of libmtr_hip.so: the C-ABI of include/mtr_hip.h over the gfx950 kernels.
+//
+// Data layout in HBM for one resident batch
+//   packed   2 bit/base, MSB first, every read word-aligned and followed by 3 zero words (so that the
+//            reference's one-past-the-window accesses org[L], org[L+1] read 'A' = 0: isolated semantics)
+//   woff/lens/order   per read: word offset, length, processing order (longest first: work balance)
+//   ranges   per read a slice [r_off, r_off + L/2+64) of start/end/w/DI-bits written by K1, read by K2
+//   records  per read max_rec fixed slots written by K2, compacted on the device before the copy back
+//   scratch  one slice per resident wavefront, sized for the longest read of the batch (K1Layout/K2Layout)
+// There is no CPU path: every entry point needs the HIP device the context was created on.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/mtr_hip.h"
+#include "mtr_common.h"
+#include "k1_ranges.hip.inc"
+#include "k2_units.hip.inc"
+
+static_assert(sizeof(DevRecord) == sizeof(mtr_record), "device and ABI record layouts must agree");
+static_assert(MTR_N_COUNTERS == CNT_N, "counter count");
+
+// ---- MT19937 (reference MT.h = stock mt19937ar), host-precomputed base stream -------------------------
+static void mt_bases(std::vector<uint8_t> &out, size_t n)
+{
+    uint32_t s[624];
+    s[0] = 0u;                                                   // init_genrand(0), fill_directional_index.c:140
+    for (int i = 1; i < 624; i++) s[i] = 1812433253u * (s[i - 1] ^ (s[i - 1] >> 30)) + (uint32_t)i;
+    int idx = 624;
+    out.resize(n);
+    for (size_t t = 0; t < n; t++) {
+        if (idx >= 624) {
+            for (int i = 0; i < 624; i++) {
+                uint32_t y = (s[i] & 0x80000000u) | (s[(i + 1) % 624] & 0x7fffffffu);
+                s[i] = s[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = s[idx++];
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        out[t] = (uint8_t)(y % 4u);                              // random_base(), fill_directional_index.c:131
+    }
+}
+
+struct mtr_ctx {
+    int device = 0, manhattan = 1; float min_ratio = 0.6f;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    std::string err;
+    int n_cu = 256;
+    uint8_t *d_mt = nullptr;
+    // resident batch
+    int n_reads = 0, Lmax = 0;
+    std::vector<int32_t> lens; std::vector<int64_t> roff;
+    uint32_t *d_packed = nullptr; int64_t *d_woff = nullptr; int32_t *d_lens = nullptr, *d_order = nullptr;
+    int64_t *d_roff = nullptr; int32_t *d_rcount = nullptr, *d_rstart = nullptr, *d_rend = nullptr, *d_rw = nullptr; uint64_t *d_rdi = nullptr;
+    int64_t total_rcap = 0;
+    DevRecord *d_records = nullptr; int32_t *d_reccount = nullptr; int max_rec = 0;
+    int32_t *d_status = nullptr; unsigned int *d_work = nullptr; unsigned long long *d_counters = nullptr;
+    uint8_t *d_scratch = nullptr; size_t scratch_bytes = 0;
+    int32_t *d_trace = nullptr; unsigned *d_trace_n = nullptr; int trace_cap = 0;
+    mtr_kernel_time kt[2] = { { 0, 0 }, { 0, 0 } };
+    unsigned long long counters[CNT_N] = { 0 };
+    bool ran = false;
+};
+
+static bool dbg() { static int v = -1; if (v < 0) v = getenv("MTR_DEBUG") ? 1 : 0; return v == 1; }
+#define DBG(...) do { if (dbg()) { fprintf(stderr, "[mtr] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return MTR_ERR_HIP; } } while (0)
+
+template <typename T> static void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+static void free_batch(mtr_ctx *ctx)
+{
+    dfree(ctx->d_packed); dfree(ctx->d_woff); dfree(ctx->d_lens); dfree(ctx->d_order);
+    dfree(ctx->d_roff); dfree(ctx->d_rcount); dfree(ctx->d_rstart); dfree(ctx->d_rend); dfree(ctx->d_rw); dfree(ctx->d_rdi);
+    dfree(ctx->d_records); dfree(ctx->d_reccount);
+    ctx->n_reads = 0; ctx->ran = false;
+}
+
+extern "C" int mtr_abi_version(void) { return MTR_ABI_VERSION; }
+
+extern "C" const char *mtr_last_error(const mtr_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+extern "C" mtr_status mtr_create(int device, int manhattan, float min_match_ratio, mtr_ctx **out)
+{
+    if (!out) return MTR_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return MTR_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return MTR_ERR_NO_DEVICE;
+    mtr_ctx *ctx = new (std::nothrow) mtr_ctx();
+    if (!ctx) return MTR_ERR_OOM;
+    ctx->device = device; ctx->manhattan = manhattan ? 1 : 0; ctx->min_ratio = min_match_ratio;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    bool ok = hipStreamCreate(&ctx->stream) == hipSuccess;
+    for (int i = 0; ok && i < 4; i++) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
+    ok = ok && hipMalloc(&ctx->d_status, sizeof(int32_t)) == hipSuccess;
+    ok = ok && hipMalloc(&ctx->d_work, sizeof(unsigned)) == hipSuccess;
+    ok = ok && hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * CNT_N) == hipSuccess;
+    ok = ok && hipMalloc(&ctx->d_trace_n, sizeof(unsigned)) == hipSuccess;
+    if (ok) {
+        // the read-independent MT19937 base stream: first min(L+4r,1e6) draws + two flanks of r <= 1e5
+        std::vector<uint8_t> mt;
+        mt_bases(mt, (size_t)MTRC_MAX_INPUT_LENGTH + 2 * 100000 + 64);
+        ok = hipMalloc(&ctx->d_mt, mt.size()) == hipSuccess && hipMemcpy(ctx->d_mt, mt.data(), mt.size(), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) { mtr_destroy(ctx); return MTR_ERR_NO_DEVICE; }
+    *out = ctx;
+    return MTR_OK;
+}
+
+extern "C" void mtr_destroy(mtr_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    free_batch(ctx);
+    dfree(ctx->d_mt); dfree(ctx->d_status); dfree(ctx->d_work); dfree(ctx->d_counters); dfree(ctx->d_scratch);
+    dfree(ctx->d_trace); dfree(ctx->d_trace_n);
+    for (int i = 0; i < 4; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+static mtr_status ensure_scratch(mtr_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->scratch_bytes) return MTR_OK;
+    dfree(ctx->d_scratch); ctx->scratch_bytes = 0;
+    if (hipMalloc(&ctx->d_scratch, bytes) != hipSuccess) { ctx->err = "scratch allocation of " + std::to_string(bytes) + " bytes failed"; return MTR_ERR_OOM; }
+    ctx->scratch_bytes = bytes;
+    return MTR_OK;
+}
+
+// number of resident wavefronts for a kernel: as many as the reads, the per-CU occupancy and the memory allow
+static int pick_waves(mtr_ctx *ctx, int n_items, int per_cu, size_t per_wave, size_t *total)
+{
+    size_t free_b = 0, tot_b = 0;
+    if (hipMemGetInfo(&free_b, &tot_b) != hipSuccess) free_b = (size_t)8 << 30;
+    size_t budget = (size_t)((double)(free_b + ctx->scratch_bytes) * 0.7);
+    long waves = (long)ctx->n_cu * per_cu;
+    if (waves > n_items) waves = n_items;
+    if (waves < 1) waves = 1;
+    while (waves > 1 && (size_t)waves * per_wave > budget) waves = waves * 3 / 4;
+    *total = (size_t)waves * per_wave;
+    return (int)waves;
+}
+
+extern "C" mtr_status mtr_upload_batch(mtr_ctx *ctx, const uint8_t *bases, const int64_t *offsets, const int32_t *lens, int32_t n)
+{
+    if (!ctx) return MTR_ERR_BAD_ARG;
+    if (!bases || !offsets || !lens || n <= 0) { ctx->err = "null input or n_reads <= 0"; return MTR_ERR_BAD_ARG; }
+    HIPCHK(hipSetDevice(ctx->device));
+    free_batch(ctx);
+    std::vector<int64_t> woff((size_t)n);
+    int64_t words = 0; int Lmax = 0;
+    for (int i = 0; i < n; i++) {
+        if (lens[i] <= 0 || lens[i] > MTRC_MAX_SUPPORTED_LENGTH) { ctx->err = "read " + std::to_string(i) + ": length " + std::to_string(lens[i]) + " outside 1.." + std::to_string(MTRC_MAX_SUPPORTED_LENGTH); return MTR_ERR_BAD_ARG; }
+        woff[(size_t)i] = words; words += lens[i] / 16 + 4;
+        Lmax = std::max(Lmax, (int)lens[i]);
+    }
+    std::vector<uint32_t> packed((size_t)words, 0u);
+    for (int i = 0; i < n; i++) {
+        const uint8_t *b = bases + offsets[i]; uint32_t *w = packed.data() + woff[(size_t)i];
+        for (int p = 0; p < lens[i]; p++) {
+            if (b[p] > 3) { ctx->err = "read " + std::to_string(i) + ": base code > 3"; return MTR_ERR_BAD_ARG; }
+            w[p >> 4] |= (uint32_t)b[p] << (30 - 2 * (p & 15));
+        }
+    }
+    std::vector<int32_t> order((size_t)n); std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });
+    ctx->roff.assign((size_t)n + 1, 0);
+    for (int i = 0; i < n; i++) ctx->roff[(size_t)i + 1] = ctx->roff[(size_t)i] + mtrc_range_cap(lens[i]);
+    ctx->total_rcap = ctx->roff[(size_t)n];
+    ctx->lens.assign(lens, lens + n);
+    ctx->n_reads = n; ctx->Lmax = Lmax;
+    ctx->max_rec = 16 + Lmax / 100;
+    HIPCHK(hipMalloc(&ctx->d_packed, packed.size() * 4));
+    HIPCHK(hipMalloc(&ctx->d_woff, (size_t)n * 8)); HIPCHK(hipMalloc(&ctx->d_lens, (size_t)n * 4)); HIPCHK(hipMalloc(&ctx->d_order, (size_t)n * 4));
+    HIPCHK(hipMalloc(&ctx->d_roff, ((size_t)n + 1) * 8)); HIPCHK(hipMalloc(&ctx->d_rcount, (size_t)n * 4));
+    HIPCHK(hipMalloc(&ctx->d_rstart, (size_t)ctx->total_rcap * 4)); HIPCHK(hipMalloc(&ctx->d_rend, (size_t)ctx->total_rcap * 4));
+    HIPCHK(hipMalloc(&ctx->d_rw, (size_t)ctx->total_rcap * 4)); HIPCHK(hipMalloc(&ctx->d_rdi, (size_t)ctx->total_rcap * 8));
+    HIPCHK(hipMalloc(&ctx->d_records, (size_t)n * (size_t)ctx->max_rec * sizeof(DevRecord)));
+    HIPCHK(hipMalloc(&ctx->d_reccount, (size_t)n * 4));
+    HIPCHK(hipMemcpyAsync(ctx->d_packed, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_woff, woff.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_lens, lens, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_roff, ctx->roff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return MTR_OK;
+}
+
+static BatchView view(const mtr_ctx *ctx)
+{
+    BatchView b; b.packed = ctx->d_packed; b.woff = ctx->d_woff; b.lens = ctx->d_lens; b.order = ctx->d_order; b.n_reads = ctx->n_reads;
+    return b;
+}
+
+static mtr_status check_status(mtr_ctx *ctx)
+{
+    int32_t st = 0;
+    HIPCHK(hipMemcpy(&st, ctx->d_status, 4, hipMemcpyDeviceToHost));
+    switch (st) {
+    case DEV_OK: return MTR_OK;
+    case DEV_ERR_RANGE_OVERFLOW: ctx->err = "a read produced more candidate ranges than L/2+64"; return MTR_ERR_OVERFLOW;
+    case DEV_ERR_RECORD_OVERFLOW: ctx->err = "a read produced more records than the per-read capacity"; return MTR_ERR_OVERFLOW;
+    case DEV_ERR_DP_TOO_LARGE: ctx->err = "You need to increse the value of WrapDPsize. (a DP exceeded the reference's 2e8 cells)"; return MTR_ERR_DP_TOO_LARGE;
+    default: ctx->err = "internal device error " + std::to_string(st); return MTR_ERR_HIP;
+    }
+}
+
+static mtr_status launch_k1(mtr_ctx *ctx)
+{
+    K1Layout y = k1_layout(ctx->Lmax);
+    size_t total = 0;
+    int waves = pick_waves(ctx, ctx->n_reads, 2, y.total, &total);
+    mtr_status s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;
+    K1Args a;
+    a.b = view(ctx); a.mt = ctx->d_mt; a.manhattan = ctx->manhattan; a.Lmax = ctx->Lmax;
+    a.scratch = ctx->d_scratch; a.scratch_per_wave = y.total;
+    a.r_count = ctx->d_rcount; a.r_off = ctx->d_roff; a.r_start = ctx->d_rstart; a.r_end = ctx->d_rend; a.r_w = ctx->d_rw; a.r_di = ctx->d_rdi;
+    a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
+    HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL(mtr_k1_ranges, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+    return MTR_OK;
+}
+
+static mtr_status launch_k2(mtr_ctx *ctx)
+{
+    K2Layout y = k2_layout(ctx->Lmax);
+    size_t total = 0;
+    int waves = pick_waves(ctx, ctx->n_reads, 6, y.total, &total);
+    mtr_status s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;
+    K2Args a;
+    a.b = view(ctx); a.min_match_ratio = ctx->min_ratio; a.Lmax = ctx->Lmax;
+    a.scratch = ctx->d_scratch; a.scratch_per_wave = y.total;
+    a.r_count = ctx->d_rcount; a.r_off = ctx->d_roff; a.r_start = ctx->d_rstart; a.r_end = ctx->d_rend; a.r_w = ctx->d_rw;
+    a.records = ctx->d_records; a.max_rec_per_read = ctx->max_rec; a.rec_count = ctx->d_reccount;
+    a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
+    a.trace = ctx->d_trace; a.trace_cap = ctx->trace_cap; a.trace_n = ctx->d_trace_n;
+    HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_trace_n, 0, sizeof(unsigned), ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    hipLaunchKernelGGL(mtr_k2_units, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+    return MTR_OK;
+}
+
+extern "C" mtr_status mtr_run_resident(mtr_ctx *ctx)
+{
+    if (!ctx) return MTR_ERR_BAD_ARG;
+    if (ctx->n_reads <= 0) { ctx->err = "no batch uploaded"; return MTR_ERR_BAD_ARG; }
+    HIPCHK(hipSetDevice(ctx->device));
+    // both kernels share one scratch arena: size it for the larger user before anything is launched
+    {
+        K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
+        size_t t1 = 0, t2 = 0;
+        (void)pick_waves(ctx, ctx->n_reads, 2, y1.total, &t1); (void)pick_waves(ctx, ctx->n_reads, 6, y2.total, &t2);
+        mtr_status s = ensure_scratch(ctx, std::max(t1, t2)); if (s != MTR_OK) return s;
+    }
+    HIPCHK(hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
+    mtr_status s = launch_k1(ctx); if (s != MTR_OK) return s;
+    s = launch_k2(ctx); if (s != MTR_OK) return s;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->kt[0].ms = ms; ctx->kt[0].launches = 1;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->kt[1].ms = ms; ctx->kt[1].launches = 1;
+    HIPCHK(hipMemcpy(ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
+    ctx->ran = true;
+    return check_status(ctx);
+}
+
+__global__ void mtr_k_compact(const DevRecord *in, const int32_t *cnt, const int64_t *off, int max_rec, int n_reads, DevRecord *out)
+{
+    // one block per read; records are copied as 16-byte words
+    int rd = blockIdx.x;
+    if (rd >= n_reads) return;
+    int c = cnt[rd];
+    const uint4 *src = (const uint4 *)(in + (size_t)rd * (size_t)max_rec);
+    uint4 *dst = (uint4 *)(out + off[rd]);
+    size_t words = (size_t)c * sizeof(DevRecord) / 16;
+    for (size_t t = threadIdx.x; t < words; t += blockDim.x) dst[t] = src[t];
+}
+
+extern "C" mtr_status mtr_fetch_results(mtr_ctx *ctx, mtr_record **out_records, int32_t **out_counts, int64_t *out_total)
+{
+    if (!ctx || !out_records || !out_counts) return MTR_ERR_BAD_ARG;
+    if (!ctx->ran) { ctx->err = "nothing has been run"; return MTR_ERR_BAD_ARG; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = ctx->n_reads;
+    int32_t *counts = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    if (!counts) return MTR_ERR_OOM;
+    HIPCHK(hipMemcpy(counts, ctx->d_reccount, (size_t)n * 4, hipMemcpyDeviceToHost));
+    std::vector<int64_t> off((size_t)n + 1, 0);
+    for (int i = 0; i < n; i++) off[(size_t)i + 1] = off[(size_t)i] + counts[i];
+    const int64_t total = off[(size_t)n];
+    mtr_record *recs = (mtr_record *)malloc(sizeof(mtr_record) * (size_t)std::max<int64_t>(total, 1));
+    if (!recs) { free(counts); return MTR_ERR_OOM; }
+    if (total > 0) {
+        DevRecord *d_out = nullptr; int64_t *d_off = nullptr;
+        HIPCHK(hipMalloc(&d_out, (size_t)total * sizeof(DevRecord)));
+        HIPCHK(hipMalloc(&d_off, ((size_t)n + 1) * 8));
+        HIPCHK(hipMemcpyAsync(d_off, off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(mtr_k_compact, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->d_records, ctx->d_reccount, d_off, ctx->max_rec, n, d_out);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(recs, d_out, (size_t)total * sizeof(DevRecord), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(d_out); (void)hipFree(d_off);
+    }
+    *out_records = recs; *out_counts = counts; if (out_total) *out_total = total;
+    return MTR_OK;
+}
+
+extern "C" mtr_status mtr_process_batch(mtr_ctx *ctx, const uint8_t *bases, const int64_t *offsets, const int32_t *lens,
+                                        int32_t n_reads, mtr_record **out_records, int32_t **out_counts, int64_t *out_total)
+{
+    mtr_status s = mtr_upload_batch(ctx, bases, offsets, lens, n_reads); if (s != MTR_OK) return s;
+    s = mtr_run_resident(ctx); if (s != MTR_OK) return s;
+    return mtr_fetch_results(ctx, out_records, out_counts, out_total);
+}
+
+extern "C" void mtr_free_results(mtr_record *records, int32_t *counts) { free(records); free(counts); }
+
+extern "C" mtr_status mtr_get_kernel_times(const mtr_ctx *ctx, mtr_kernel_time *out, int32_t n)
+{
+    if (!ctx || !out) return MTR_ERR_BAD_ARG;
+    for (int i = 0; i < n && i < 2; i++) out[i] = ctx->kt[i];
+    return MTR_OK;
+}
+
+extern "C" mtr_status mtr_get_counters(const mtr_ctx *ctx, int64_t *out, int32_t n)
+{
+    if (!ctx || !out) return MTR_ERR_BAD_ARG;
+    for (int i = 0; i < n && i < CNT_N; i++) out[i] = (int64_t)ctx->counters[i];
+    return MTR_OK;
+}
+
+extern "C" mtr_status mtr_test_ranges(mtr_ctx *ctx, int32_t **out_counts, int32_t **out_start, int32_t **out_end,
+                                      int32_t **out_w, uint64_t **out_di_bits, int64_t *out_total)
+{
+    if (!ctx || !out_counts || !out_start || !out_end || !out_w || !out_di_bits) return MTR_ERR_BAD_ARG;
+    if (ctx->n_reads <= 0) { ctx->err = "no batch uploaded"; return MTR_ERR_BAD_ARG; }
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
+    mtr_status s = launch_k1(ctx); if (s != MTR_OK) return s;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->kt[0].ms = ms; ctx->kt[0].launches = 1;
+    s = check_status(ctx); if (s != MTR_OK) return s;
+    const int n = ctx->n_reads;
+    std::vector<int32_t> cnt((size_t)n), st((size_t)ctx->total_rcap), en((size_t)ctx->total_rcap), ww((size_t)ctx->total_rcap);
+    std::vector<uint64_t> di((size_t)ctx->total_rcap);
+    HIPCHK(hipMemcpy(cnt.data(), ctx->d_rcount, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(st.data(), ctx->d_rstart, st.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(en.data(), ctx->d_rend, en.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ww.data(), ctx->d_rw, ww.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(di.data(), ctx->d_rdi, di.size() * 8, hipMemcpyDeviceToHost));
+    int64_t total = 0; for (int i = 0; i < n; i++) total += cnt[(size_t)i];
+    int32_t *oc = (int32_t *)malloc((size_t)n * 4), *os = (int32_t *)malloc((size_t)std::max<int64_t>(total, 1) * 4);
+    int32_t *oe = (int32_t *)malloc((size_t)std::max<int64_t>(total, 1) * 4), *ow = (int32_t *)malloc((size_t)std::max<int64_t>(total, 1) * 4);
+    uint64_t *od = (uint64_t *)malloc((size_t)std::max<int64_t>(total, 1) * 8);
+    if (!oc || !os || !oe || !ow || !od) return MTR_ERR_OOM;
+    int64_t p = 0;
+    for (int i = 0; i < n; i++) {
+        oc[i] = cnt[(size_t)i];
+        for (int t = 0; t < cnt[(size_t)i]; t++, p++) {
+            size_t q = (size_t)ctx->roff[(size_t)i] + (size_t)t;
+            os[p] = st[q]; oe[p] = en[q]; ow[p] = ww[q]; od[p] = di[q];
+        }
+    }
+    *out_counts = oc; *out_start = os; *out_end = oe; *out_w = ow; *out_di_bits = od; if (out_total) *out_total = total;
+    return MTR_OK;
+}
+
+extern "C" mtr_status mtr_test_wrap_dp(mtr_ctx *ctx, int32_t n_tasks, const int32_t *read_idx, const int32_t *query_start,
+                                       const int32_t *query_end, const uint8_t *units, const int32_t *unit_off,
+                                       const int32_t *gain, const int32_t *mismatch, const int32_t *indel, int32_t *out8)
+{
+    if (!ctx || n_tasks <= 0 || !read_idx || !query_start || !query_end || !units || !unit_off || !gain || !mismatch || !indel || !out8) return MTR_ERR_BAD_ARG;
+    if (ctx->n_reads <= 0) { ctx->err = "no batch uploaded"; return MTR_ERR_BAD_ARG; }
+    HIPCHK(hipSetDevice(ctx->device));
+    size_t cells = 1;
+    for (int t = 0; t < n_tasks; t++) {
+        int rd = read_idx[t];
+        int U = unit_off[t + 1] - unit_off[t];
+        if (rd < 0 || rd >= ctx->n_reads || query_start[t] < 0 || query_end[t] < query_start[t] || query_end[t] >= ctx->lens[(size_t)rd] || U <= 0 || U >= MTRC_MAX_PERIOD) { ctx->err = "bad DP task " + std::to_string(t); return MTR_ERR_BAD_ARG; }
+        cells = std::max(cells, (size_t)(query_end[t] - query_start[t] + 1) * (size_t)U);
+    }
+    size_t per_wave = mtrc_align(cells, 256), total = 0;
+    int waves = pick_waves(ctx, n_tasks, 8, per_wave, &total);
+    DBG("test_wrap_dp: %d tasks, cells %zu, waves %d, scratch %zu", n_tasks, cells, waves, total);
+    mtr_status s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;
+    int32_t *d_i32 = nullptr; uint8_t *d_units = nullptr; int32_t *d_out = nullptr;
+    const size_t nt = (size_t)n_tasks;
+    HIPCHK(hipMalloc(&d_i32, (nt * 7 + 1) * 4)); HIPCHK(hipMalloc(&d_units, (size_t)unit_off[n_tasks] + 16)); HIPCHK(hipMalloc(&d_out, nt * 8 * 4));
+    int32_t *d_rd = d_i32, *d_qs = d_i32 + nt, *d_qe = d_i32 + 2 * nt, *d_g = d_i32 + 3 * nt, *d_m = d_i32 + 4 * nt, *d_d = d_i32 + 5 * nt, *d_uo = d_i32 + 6 * nt;
+    HIPCHK(hipMemcpy(d_rd, read_idx, nt * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_qs, query_start, nt * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_qe, query_end, nt * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_g, gain, nt * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_m, mismatch, nt * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_d, indel, nt * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_uo, unit_off, (nt + 1) * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_units, units, (size_t)unit_off[n_tasks], hipMemcpyHostToDevice));
+    DpTestArgs a;
+    a.b = view(ctx); a.n_tasks = n_tasks; a.read_idx = d_rd; a.qs = d_qs; a.qe = d_qe; a.units = d_units; a.unit_off = d_uo;
+    a.gain = d_g; a.mism = d_m; a.indel = d_d; a.out8 = d_out; a.scratch = ctx->d_scratch; a.scratch_per_wave = per_wave; a.cells_cap = cells;
+    a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
+    HIPCHK(hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    DBG("test_wrap_dp: launching");
+    hipLaunchKernelGGL(mtr_k_dp_test, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    DBG("test_wrap_dp: kernel done");
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->kt[1].ms = ms; ctx->kt[1].launches = 1;
+    HIPCHK(hipMemcpy(ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out8, d_out, nt * 8 * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_i32); (void)hipFree(d_units); (void)hipFree(d_out);
+    return check_status(ctx);
+}
+
+extern "C" mtr_status mtr_set_trace(mtr_ctx *ctx, int32_t max_events)
+{
+    if (!ctx || max_events < 0) return MTR_ERR_BAD_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    dfree(ctx->d_trace); ctx->trace_cap = 0;
+    if (max_events > 0) { HIPCHK(hipMalloc(&ctx->d_trace, (size_t)max_events * 16 * 4)); ctx->trace_cap = max_events; }
+    return MTR_OK;
+}
+
+extern "C" mtr_status mtr_get_trace(mtr_ctx *ctx, int32_t **out_events, int64_t *out_n)
+{
+    if (!ctx || !out_events || !out_n) return MTR_ERR_BAD_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    unsigned n = 0;
+    HIPCHK(hipMemcpy(&n, ctx->d_trace_n, 4, hipMemcpyDeviceToHost));
+    if ((int64_t)n > ctx->trace_cap) n = (unsigned)ctx->trace_cap;
+    int32_t *ev = (int32_t *)malloc((size_t)std::max(1u, n) * 16 * 4);
+    if (!ev) return MTR_ERR_OOM;
+    if (n > 0) HIPCHK(hipMemcpy(ev, ctx->d_trace, (size_t)n * 16 * 4, hipMemcpyDeviceToHost));
+    *out_events = ev; *out_n = n;
+    return MTR_OK;
+}

@@ -1,0 +1,170 @@
+// mtr_common.h — constants, argument blocks and scratch layouts shared by the host side of the
+// C-ABI (mtr_abi.hip) and the gfx950 kernels (k1_ranges.hip.inc, k2_units.hip.inc).
+//
+// Reference constants: mTR.h:31-58.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#define MTR_WAVE 64
+
+#define MTRC_MAX_PERIOD 500
+#define MTRC_MIN_PERIOD 2
+#define MTRC_MIN_NUM_FREQ_UNIT 5
+#define MTRC_MIN_WINDOW 5
+#define MTRC_MAX_WINDOW 10240
+#define MTRC_MIN_KMER 5
+#define MTRC_MAX_KMER 15
+#define MTRC_MAX_TIEBREAKS 1024
+#define MTRC_MAX_SEEDS 100
+#define MTRC_WRAP_DP_SIZE 200000000LL
+#define MTRC_MAX_INPUT_LENGTH 1000000
+#define MTRC_MAX_PASSES 20          // k=1: 5,10,20  k=3: 5..80  k=5: 5..10240
+
+// A read is usable only if L + 2r <= MAX_INPUT_LENGTH (the reference's buffers overflow beyond it).
+#define MTRC_MAX_SUPPORTED_LENGTH 833333
+
+// per-cell traceback codes of the wrap-around DP (one byte per cell in the v1 layout)
+enum { DPC_Z = 0, DPC_M = 1, DPC_X = 2, DPC_DEL = 3, DPC_INS = 4, DPC_PENDING = 5 };
+
+// device counters (index = MTR counters in include/mtr_hip.h)
+enum { CNT_DP_CALLS = 0, CNT_DP_CELLS, CNT_DP_ROWS, CNT_REV_CALLS, CNT_REV_CELLS, CNT_TABLES, CNT_LOOKUPS,
+       CNT_RANGES_CAND, CNT_RANGES_EXEC, CNT_RECORDS, CNT_DI_PASSES, CNT_DI_POS, CNT_TB_STEPS, CNT_UNDEFINED,
+       CNT_GLOBAL_TABLES, CNT_N = 16 };
+
+// status word values written by the kernels (first error wins)
+enum { DEV_OK = 0, DEV_ERR_RANGE_OVERFLOW = 1, DEV_ERR_RECORD_OVERFLOW = 2, DEV_ERR_DP_TOO_LARGE = 3, DEV_ERR_INTERNAL = 4 };
+
+static inline __host__ __device__ int mtrc_rand_len(int L) { return L < 1000 ? 100 : L / 10; }   // handle_one_read.c:194-201
+static inline __host__ __device__ size_t mtrc_align(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline __host__ __device__ int mtrc_range_cap(int L) { return L / 2 + 64; }
+
+// ---- K1 per-wave scratch layout (all offsets in bytes, 16-byte aligned) -------------------------
+struct K1Layout {
+    size_t codes[3];      // uint16 [ncode] for k = 1, 3, 5
+    size_t tmp;           // double [MAX_PASSES][n]
+    size_t di;            // double [n]
+    size_t end;           // int32  [n]
+    size_t w;             // int32  [n]
+    size_t l_pos, l_end, l_w, l_di;   // compact list: int32/int32/int32/double [cap]
+    size_t total;
+    int n, ncode, cap;
+};
+static inline __host__ __device__ K1Layout k1_layout(int Lmax)
+{
+    K1Layout y;
+    int r = mtrc_rand_len(Lmax);
+    y.n = Lmax + 2 * r;
+    long nc = (long)Lmax + 4L * r; if (nc > MTRC_MAX_INPUT_LENGTH) nc = MTRC_MAX_INPUT_LENGTH;
+    if (nc < y.n) nc = y.n;
+    // the passes read up to position L + r - k + 2w (w < L/2, w <= 10240); beyond N everything is zero
+    long wmax = Lmax / 2 < MTRC_MAX_WINDOW ? Lmax / 2 : MTRC_MAX_WINDOW;
+    long reach = (long)Lmax + r + 2 * wmax + 8;
+    if (nc < reach) nc = reach;
+    y.ncode = (int)nc + 16;
+    y.cap = mtrc_range_cap(Lmax) + Lmax / 2;    // every alive entry (also those ending beyond the read)
+    size_t o = 0;
+    for (int i = 0; i < 3; i++) { y.codes[i] = o; o = mtrc_align(o + (size_t)y.ncode * 2, 16); }
+    y.tmp = o;  o = mtrc_align(o + (size_t)MTRC_MAX_PASSES * (size_t)y.n * 8, 16);
+    y.di = o;   o = mtrc_align(o + (size_t)y.n * 8, 16);
+    y.end = o;  o = mtrc_align(o + (size_t)y.n * 4, 16);
+    y.w = o;    o = mtrc_align(o + (size_t)y.n * 4, 16);
+    y.l_pos = o; o = mtrc_align(o + (size_t)y.cap * 4, 16);
+    y.l_end = o; o = mtrc_align(o + (size_t)y.cap * 4, 16);
+    y.l_w = o;   o = mtrc_align(o + (size_t)y.cap * 4, 16);
+    y.l_di = o;  o = mtrc_align(o + (size_t)y.cap * 8, 16);
+    y.total = mtrc_align(o, 256);
+    return y;
+}
+
+// ---- K2 per-wave scratch layout ------------------------------------------------------------------
+#define K2_NSLOT 4                 // unit slots: 0 = best of range, 1 = best of k, 2 = candidate, 3 = revision tmp
+#define K2_SLOT_UNIT 1024          // bytes of unit codes per slot (a revised unit can reach 2*499)
+#define K2_SLOT_SCORE 512          // int32 per slot
+struct K2Layout {
+    size_t codes;                  // uint8 [cells]  traceback codes
+    size_t unit[K2_NSLOT];         // uint8 [1024]
+    size_t score[K2_NSLOT];        // int32 [512]
+    size_t cons, miss;             // int32 [501*5], [501*4]
+    size_t pol_u, pol_rev;         // int32 [512] each (polish work arrays)
+    size_t gkeys, gvals;           // int32 [gcap] global-memory k-mer table for windows that do not fit LDS
+    size_t total;
+    size_t cells; unsigned gcap;
+};
+static inline __host__ __device__ size_t k2_max_cells(int Lmax)
+{
+    // rows <= L, unit <= min(499, 2*rows/5) (revision can double a unit of <= rows/5 bases)
+    long long u = 2LL * Lmax / 5 + 2; if (u > 499) u = 499;
+    long long c = (long long)(Lmax + 2) * u;
+    if (c > MTRC_WRAP_DP_SIZE) c = MTRC_WRAP_DP_SIZE;
+    return (size_t)c;
+}
+static inline __host__ __device__ K2Layout k2_layout(int Lmax)
+{
+    K2Layout y;
+    y.cells = k2_max_cells(Lmax);
+    unsigned g = 64; while (g < 2u * (unsigned)(Lmax + 2)) g <<= 1;
+    y.gcap = g;
+    size_t o = 0;
+    y.codes = o; o = mtrc_align(o + y.cells, 256);
+    for (int i = 0; i < K2_NSLOT; i++) { y.unit[i] = o; o = mtrc_align(o + K2_SLOT_UNIT, 16); }
+    for (int i = 0; i < K2_NSLOT; i++) { y.score[i] = o; o = mtrc_align(o + K2_SLOT_SCORE * 4, 16); }
+    y.cons = o; o = mtrc_align(o + 501 * 5 * 4, 16);
+    y.miss = o; o = mtrc_align(o + 501 * 4 * 4, 16);
+    y.pol_u = o; o = mtrc_align(o + 512 * 4, 16);
+    y.pol_rev = o; o = mtrc_align(o + 1024 * 4, 16);   // also holds a revised unit (<= 2*499 bases)
+    y.gkeys = o; o = mtrc_align(o + (size_t)g * 4, 16);
+    y.gvals = o; o = mtrc_align(o + (size_t)g * 4, 16);
+    y.total = mtrc_align(o, 256);
+    return y;
+}
+
+// ---- device record (same memory layout as mtr_record in include/mtr_hip.h) ------------------------
+struct DevRecord {
+    int32_t f[14];                 // rep_start .. indel_penalty, reserved
+    char    unit[MTRC_MAX_PERIOD + 4];
+    int32_t unit_score[MTRC_MAX_PERIOD];
+};
+
+// ---- kernel argument blocks -------------------------------------------------------------------------
+struct BatchView {
+    const uint32_t *packed;        // 2 bit/base, MSB first, every read starts on a word and is followed by >= 3 zero words
+    const int64_t  *woff;          // word offset of every read
+    const int32_t  *lens;
+    const int32_t  *order;         // processing order (longest first)
+    int32_t n_reads;
+};
+
+struct K1Args {
+    BatchView b;
+    const uint8_t *mt;             // MT19937(seed 0) % 4 stream (MT.h; fill_directional_index.c:129-131)
+    int32_t manhattan;
+    int32_t Lmax;
+    uint8_t *scratch; size_t scratch_per_wave;
+    // outputs: usable ranges per read
+    int32_t *r_count; const int64_t *r_off;
+    int32_t *r_start, *r_end, *r_w; uint64_t *r_di;
+    int32_t *status; unsigned int *work_counter; unsigned long long *counters;
+};
+
+struct K2Args {
+    BatchView b;
+    float min_match_ratio;
+    int32_t Lmax;
+    uint8_t *scratch; size_t scratch_per_wave;
+    const int32_t *r_count; const int64_t *r_off;
+    const int32_t *r_start; int32_t *r_end; const int32_t *r_w;    // r_end is overwritten (-1 = pruned)
+    DevRecord *records; int32_t max_rec_per_read; int32_t *rec_count;
+    int32_t *status; unsigned int *work_counter; unsigned long long *counters;
+    int32_t *trace; int32_t trace_cap; unsigned int *trace_n;
+};
+
+struct DpTestArgs {
+    BatchView b;
+    int32_t n_tasks;
+    const int32_t *read_idx, *qs, *qe; const uint8_t *units; const int32_t *unit_off;
+    const int32_t *gain, *mism, *indel;
+    int32_t *out8;
+    uint8_t *scratch; size_t scratch_per_wave; size_t cells_cap;
+    int32_t *status; unsigned int *work_counter; unsigned long long *counters;
+};

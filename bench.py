@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — reads/s of the per-read hot path (handle_one_read) on MI355X, next to CPU mTR.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path (kernel K1 ranges + kernel K2 units/DP, mtr_run_resident) over one batch of
+synthetic reads that is already resident in HBM (2 bit/base).  Workload = the configuration BASELINE.json's
+metric is quoted on: 10 000 synthetic Nanopore-error reads of ~2 kb (unit 100 x 10 copies, 500-base flanks;
+mtr_amd.synth "headline2k") per GPU.  With N GPUs every rank holds its own 10 000 reads (weak scaling, no
+data-path collective); the step ends with the RCCL gather of the per-read record tables to rank 0 (the one
+exchange step of the path).  Rank 0 prints ONE JSON line.
+
+roofline: the dominant kernel is K2.  `achieved` = algorithmic HBM bytes of one launch (SURVEY.md §8d:
+B_alg = ceil(L/4) + 576 R + sum over DPs of ceil(cells/2), every DP counted as spilled because this build keeps
+all traceback codes in HBM-backed scratch) / K2's average duration measured with HIP events on the launch stream.
+The path is NOT HBM-bound (integer VALU + cross-lane scan latency): the VALU-side figure is reported in
+`roofline.valu` from the counted DP cell updates.  `traffic` = HBM bytes/launch from the rocprofv3 PMC passes
+recorded in profiles/ (null until measured).
+cpu_baseline: rank 0, N=1 only — the reference mTR binary (oracle/_ref/mTR_ref, kind "reference") when it
+travelled with the repo, else the CPU oracle (kind "port"), on the first reads of the same workload, 1 core.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+READS_PER_GPU = 10000
+WORKLOAD = "headline2k"
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz = 78.6 T lane-ops/s
+OPS_PER_CELL = 7                 # ~7 integer ops per DP cell update
+
+
+def cpu_baseline(reads, n_sample):
+    """Time CPU mTR on the first n_sample reads (1 core).  Returns the cpu_baseline object."""
+    from mtr_amd import synth
+
+    sample = [(str(i), reads[i]) for i in range(min(n_sample, len(reads)))]
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mTR_ref")
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, "sample.fa")
+        synth.write_fasta(fa, sample)
+        if os.path.exists(ref_bin) and os.access(ref_bin, os.X_OK):
+            kind, cmd = "reference", [ref_bin, fa]
+        else:
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True)
+            kind, cmd = "port", [os.path.join(ROOT, "oracle", "mtr_oracle_cli"), fa]
+        t0 = time.perf_counter()
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dt = time.perf_counter() - t0
+    return {"value": len(sample) / dt, "unit": "reads/s", "cores": 1, "kind": kind,
+            "sample": f"first {len(sample)} reads of the workload, one process, {dt:.1f} s"}
+
+
+def measured_traffic():
+    """HBM bytes per K2 launch from the committed rocprofv3 PMC summary (profiles/pmc_latest.json), or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(p) as fh:
+            return float(json.load(fh)["k2_hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=READS_PER_GPU, help="reads per GPU (default = the headline workload)")
+    ap.add_argument("--cpu-sample", type=int, default=800, help="reads timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--no-latency", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import mtr_amd
+    from mtr_amd import synth
+    from mtr_amd.dist import RECORD_BYTES, gather_records
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world == 1:
+        print("bench.py: --gpus > 1 needs torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # every rank owns its own block of reads (weak scaling): same distribution, different seed
+    reads = [c for _, c in synth.make_reads(WORKLOAD, a.reads, seed=2 + rank)]
+    eng = mtr_amd.Engine(device=local_rank)
+    eng.upload(reads)                                   # inputs resident in HBM before the timed region
+
+    rec_buf = None
+
+    def step():
+        nonlocal rec_buf
+        eng.run()
+        if world > 1:
+            # exchange step: gather the per-read record tables to rank 0 over RCCL
+            total = eng.counters()["records"]
+            if rec_buf is None or rec_buf.numel() < total * RECORD_BYTES:
+                rec_buf = torch.empty(max(total, 1) * RECORD_BYTES * 5 // 4, dtype=torch.uint8, device="cuda")
+            counts, tot = eng.export_records_device(rec_buf.data_ptr(), rec_buf.numel() // RECORD_BYTES)
+            gather_records(rec_buf[: tot * RECORD_BYTES], torch.from_numpy(counts).cuda(), dst=0)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    k2_ms, k1_ms = [], []
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        kt = eng.kernel_times_ms()
+        k1_ms.append(kt["k1_ranges"])
+        k2_ms.append(kt["k2_units"])
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        cnt = eng.counters()
+        n_local = len(reads)
+        total_reads = n_local * world * a.steps
+        value = total_reads / dt
+        # algorithmic bytes of one K2 launch (this rank's batch)
+        sumL4 = sum((len(r) + 3) // 4 for r in reads)
+        b_alg = sumL4 + 576 * cnt["records"] + (cnt["dp_cells"] + cnt["revise_dp_cells"] + 1) // 2
+        k2_avg_s = float(np.mean(k2_ms)) / 1e3
+        achieved_gbs = b_alg / k2_avg_s / 1e9
+        cells = cnt["dp_cells"] + cnt["revise_dp_cells"]
+        valu_ops = cells * OPS_PER_CELL / k2_avg_s
+        out = {
+            "metric": "reads/sec, 2 kb Nanopore synthetic",
+            "value": value,
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": f"{WORKLOAD}: {n_local} synthetic Nanopore reads per GPU, unit 100 x 10 copies, 500-base flanks, "
+                                   f"mean L {np.mean([len(r) for r in reads]):.0f}, error profile sub 1.6/ins 9.0/del 3.8 %",
+                       "reads_per_gpu": n_local, "parallelism": f"reads sharded over {world} GPU(s), gather to rank 0"},
+            "ms_per_read": dt / a.steps * 1e3 / n_local,
+            "kernels_ms": {"k1_ranges": float(np.mean(k1_ms)), "k2_units": float(np.mean(k2_ms))},
+            "work_per_launch": {k: cnt[k] for k in ("dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_dp_cells",
+                                                    "kmer_tables", "kmer_lookups", "ranges_executed", "records", "traceback_steps")},
+            "roofline": {"bound": "hbm", "kernel": "mtr_k2_units", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(),
+                         "algorithmic_bytes_per_launch": b_alg,
+                         "valu": {"achieved_lane_ops_per_s": valu_ops, "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                                  "frac": valu_ops / VALU_PEAK_LANE_OPS, "cells_per_launch": cells, "ops_per_cell": OPS_PER_CELL},
+                         "note": "not HBM-bound: row-serial integer max-plus recurrence (VALU + cross-lane scan latency)"},
+        }
+        if world == 1 and not a.no_latency:
+            lat = []
+            e2 = mtr_amd.Engine(device=local_rank)
+            for i in range(33):
+                t1 = time.perf_counter()
+                e2.process([reads[i]])
+                lat.append((time.perf_counter() - t1) * 1e3)
+            e2.close()
+            out["latency_ms_per_read_p50"] = float(np.median(lat[1:]))
+        if world == 1 and a.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(reads, a.cpu_sample)
+            out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,6 +95,11 @@ mtr_status mtr_upload_batch(mtr_ctx *ctx, const uint8_t *bases, const int64_t *o
 mtr_status mtr_run_resident(mtr_ctx *ctx);
 mtr_status mtr_fetch_results(mtr_ctx *ctx, mtr_record **out_records, int32_t **out_counts, int64_t *out_total);
 
+/* Multi-GPU plumbing: compacts the records of the last run (read after read, insertion order) into
+ * caller-owned DEVICE memory on the context's GPU (capacity in records) so that the caller can hand it
+ * to RCCL without a host round trip; counts_host receives n_reads per-read counts. */
+mtr_status mtr_export_records_device(mtr_ctx *ctx, void *d_dst, int64_t capacity_records, int32_t *counts_host, int64_t *out_total);
+
 /* Per-kernel device time of the last mtr_run_resident()/mtr_process_batch(), measured with HIP events
  * on the stream the kernels were launched on.  Kernel ids: 0 = ranges (K1), 1 = units+DP (K2). */
 typedef struct mtr_kernel_time { float ms; int32_t launches; } mtr_kernel_time;

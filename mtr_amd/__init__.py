@@ -23,7 +23,7 @@ COUNTER_NAMES = ["dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_d
                  "undefined_guards", "global_tables", "reserved"]
 EXPORTS = ["mtr_create", "mtr_destroy", "mtr_last_error", "mtr_abi_version", "mtr_process_batch", "mtr_free_results",
            "mtr_upload_batch", "mtr_run_resident", "mtr_fetch_results", "mtr_get_kernel_times", "mtr_get_counters",
-           "mtr_test_ranges", "mtr_test_wrap_dp", "mtr_set_trace", "mtr_get_trace"]
+           "mtr_test_ranges", "mtr_test_wrap_dp", "mtr_set_trace", "mtr_get_trace", "mtr_export_records_device"]
 
 
 class MtrError(RuntimeError):
@@ -98,6 +98,8 @@ def load_library(path: str = LIB_PATH):
     lib.mtr_test_ranges.restype = C.c_int
     lib.mtr_test_wrap_dp.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 9
     lib.mtr_test_wrap_dp.restype = C.c_int
+    lib.mtr_export_records_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, P(C.c_int64)]
+    lib.mtr_export_records_device.restype = C.c_int
     lib.mtr_set_trace.argtypes = [C.c_void_p, C.c_int32]
     lib.mtr_set_trace.restype = C.c_int
     lib.mtr_get_trace.argtypes = [C.c_void_p, P(P(C.c_int32)), P(C.c_int64)]
@@ -194,6 +196,14 @@ class Engine:
                                   r.unit.decode(), tuple(r.unit_score[:max(0, min(per, MAX_PERIOD))])))
             out.append(lst)
         return out
+
+    def export_records_device(self, device_ptr: int, capacity_records: int):
+        """Compacts the last run's records into caller-owned device memory; returns (counts int32[n_reads], total)."""
+        counts = np.zeros(self.n_reads, np.int32)
+        total = C.c_int64()
+        self._check(self.lib.mtr_export_records_device(self.h, C.c_void_p(device_ptr), capacity_records, counts.ctypes.data, C.byref(total)),
+                    "mtr_export_records_device")
+        return counts, int(total.value)
 
     # ---- measurements ------------------------------------------------------------------------------------
     def kernel_times_ms(self):

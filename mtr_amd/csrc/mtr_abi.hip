@@ -324,6 +324,30 @@ extern "C" mtr_status mtr_fetch_results(mtr_ctx *ctx, mtr_record **out_records, 
     return MTR_OK;
 }
 
+// Multi-GPU plumbing: compact the records of the last run into caller-owned DEVICE memory (e.g. a torch
+// uint8 tensor that RCCL then gathers to rank 0); counts go to host.
+extern "C" mtr_status mtr_export_records_device(mtr_ctx *ctx, void *d_dst, int64_t capacity_records, int32_t *counts_host, int64_t *out_total)
+{
+    if (!ctx || !counts_host || !out_total) return MTR_ERR_BAD_ARG;
+    if (!ctx->ran) { ctx->err = "nothing has been run"; return MTR_ERR_BAD_ARG; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = ctx->n_reads;
+    HIPCHK(hipMemcpy(counts_host, ctx->d_reccount, (size_t)n * 4, hipMemcpyDeviceToHost));
+    std::vector<int64_t> off((size_t)n + 1, 0);
+    for (int i = 0; i < n; i++) off[(size_t)i + 1] = off[(size_t)i] + counts_host[i];
+    *out_total = off[(size_t)n];
+    if (off[(size_t)n] == 0) return MTR_OK;
+    if (!d_dst || off[(size_t)n] > capacity_records) { ctx->err = "destination holds " + std::to_string(capacity_records) + " records, " + std::to_string(off[(size_t)n]) + " needed"; return MTR_ERR_OVERFLOW; }
+    int64_t *d_off = nullptr;
+    HIPCHK(hipMalloc(&d_off, ((size_t)n + 1) * 8));
+    HIPCHK(hipMemcpyAsync(d_off, off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(mtr_k_compact, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->d_records, ctx->d_reccount, d_off, ctx->max_rec, n, (DevRecord *)d_dst);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_off);
+    return MTR_OK;
+}
+
 extern "C" mtr_status mtr_process_batch(mtr_ctx *ctx, const uint8_t *bases, const int64_t *offsets, const int32_t *lens,
                                         int32_t n_reads, mtr_record **out_records, int32_t **out_counts, int64_t *out_total)
 {

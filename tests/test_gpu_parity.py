@@ -1,0 +1,195 @@
+"""Parity of the HIP path (through the C-ABI of include/mtr_hip.h) — run on the MI355X box with -m gpu.
+
+Three kinds of evidence:
+  1. against the golden vectors recorded from the unmodified reference (tests/golden): candidate ranges
+     (G1), wrap-around DP calls (G3) and the inserted records (G4 = the 17 arguments of
+     insert_an_alignment_into_set), in Manhattan and Pearson (-p) mode — bit-exact;
+  2. against the CPU oracle (oracle/mtr_oracle.c, itself pinned to the same vectors) on seeded synthetic
+     reads at sizes the oracle finishes in seconds — bit-exact;
+  3. at BASELINE.json's full size (10 000 reads of ~2 kb) through size-independent properties: batch
+     independence (a read's records do not depend on which reads share its batch, nor on their order),
+     run-to-run determinism, and a random sample against the oracle.
+"""
+import numpy as np
+import pytest
+
+import mtr_amd
+from mtr_amd import synth
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = mtr_amd.Engine()
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng_p():
+    e = mtr_amd.Engine(manhattan=False)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from tests.oracle_binding import Oracle
+    return Oracle()
+
+
+def _diff_msg(i, want, got):
+    msg = [f"read {i}: {len(want)} records expected, {len(got)} produced"]
+    for a, b in zip(want, got):
+        if a != b:
+            for k, (x, y) in enumerate(zip(a, b)):
+                if x != y:
+                    msg.append(f"  field {k}: want {str(x)[:120]} got {str(y)[:120]}")
+            break
+    return "\n".join(msg)
+
+
+# ---- 1. golden vectors of the reference ----------------------------------------------------------------------
+@pytest.mark.parametrize("name,mode", gu.cases())
+def test_records_match_reference_golden(eng, eng_p, name, mode):
+    e = eng if mode == "default" else eng_p
+    reads = gu.read_fasta(gu.input_path(name))
+    cap = gu.capture_by_read(name, mode)
+    assert len(cap) == len(reads)
+    got = e.process([c for _, c in reads])
+    for i, (per_read, g) in enumerate(zip(cap, got)):
+        want = [gu.g4_tuple(ev) for ev in per_read["G4"]]
+        assert [tuple(r) for r in g] == want, _diff_msg(i, want, [tuple(r) for r in g])
+
+
+@pytest.mark.parametrize("name,mode", gu.cases())
+def test_ranges_match_reference_golden(eng, eng_p, name, mode):
+    e = eng if mode == "default" else eng_p
+    reads = gu.read_fasta(gu.input_path(name))
+    cap = gu.capture_by_read(name, mode)
+    e.upload([c for _, c in reads])
+    got = e.test_ranges()
+    for i, per_read in enumerate(cap):
+        assert got[i] == gu.g1_usable(per_read["G1"]), f"read {i} of {name} [{mode}]"
+
+
+def test_dp_calls_match_reference_golden(eng):
+    """Every wrap_around_DP_sub call the reference made on the fixture reads (G3), replayed on the DP kernel."""
+    lut = {"A": 0, "C": 1, "G": 2, "T": 3}
+    total = 0
+    for name in ("synth_c2", "synth_2k", "synth_c4", "edge", "3_5", "2_5_10_20_set", "10_50", "20_50"):
+        reads = gu.read_fasta(gu.input_path(name))
+        cap = gu.capture_by_read(name, "default")
+        eng.upload([c for _, c in reads])
+        tasks, want = [], []
+        for i, per_read in enumerate(cap):
+            for ev in per_read["G3"]:
+                if len(ev["unit"]) == 0:
+                    continue
+                tasks.append((i, ev["qs"], min(ev["qe"], len(reads[i][1]) - 1), np.array([lut[ch] for ch in ev["unit"]], np.uint8), ev["G"], ev["MM"], ev["D"]))
+                want.append((tuple(ev["out"]), ev["qe"]))
+        # the revision DP may run one base past the read; the test entry point takes in-read windows only
+        keep = [k for k, (_, qe) in enumerate(want) if qe == tasks[k][2]]
+        tasks = [tasks[k] for k in keep]
+        want = [want[k][0] for k in keep]
+        out = eng.test_wrap_dp(tasks)
+        bad = [k for k in range(len(tasks)) if tuple(int(x) for x in out[k]) != want[k]]
+        assert not bad, f"{name}: {len(bad)} of {len(tasks)} DP calls differ, first: task {tasks[bad[0]][:3]} want {want[bad[0]]} got {out[bad[0]]}"
+        total += len(tasks)
+    assert total > 5000
+
+
+# ---- 2. the oracle on seeded synthetic reads -------------------------------------------------------------------
+@pytest.mark.parametrize("config,n,seed,manhattan", [("c2", 300, 11, True), ("headline2k", 150, 12, True), ("c4", 300, 14, True),
+                                                      ("c2", 150, 21, False), ("c4", 150, 24, False)])
+def test_records_match_oracle(eng, eng_p, config, n, seed, manhattan):
+    from tests.oracle_binding import Oracle
+    orc = Oracle(manhattan=manhattan)
+    reads = [c for _, c in synth.make_reads(config, n, seed)]
+    got = (eng if manhattan else eng_p).process(reads)
+    bad = []
+    for i, codes in enumerate(reads):
+        want = orc.process(codes)
+        if [tuple(r) for r in got[i]] != want:
+            bad.append(_diff_msg(i, want, [tuple(r) for r in got[i]]))
+    orc.close()
+    assert not bad, f"{len(bad)} of {n} reads differ\n" + "\n".join(bad[:3])
+
+
+def test_min_match_ratio_option(oracle):
+    from tests.oracle_binding import Oracle
+    orc = Oracle(min_match_ratio=0.8)
+    e = mtr_amd.Engine(min_match_ratio=0.8)
+    reads = [c for _, c in synth.make_reads("c2", 40, 31)]
+    got = e.process(reads)
+    for i, codes in enumerate(reads):
+        assert [tuple(r) for r in got[i]] == orc.process(codes)
+    e.close()
+    orc.close()
+
+
+def test_long_read_config3_shape(eng, oracle):
+    """unit 200 x 200 copies (L ~ 42 kb): multi-chunk DP rows, DPs of millions of cells, large windows -> global tables."""
+    reads = [c for _, c in synth.make_reads("c3", 1, 3)]
+    got = eng.process(reads)
+    want = oracle.process(reads[0])
+    assert [tuple(r) for r in got[0]] == want, _diff_msg(0, want, [tuple(r) for r in got[0]])
+    assert eng.counters()["global_tables"] > 0
+
+
+def test_mixed_length_batch(eng, oracle):
+    """very short and long reads in one batch: scratch is sized by the longest, results by each read alone"""
+    rng = np.random.RandomState(5)
+    reads = [c for _, c in synth.make_reads("c2", 6, 41)]
+    reads += [rng.randint(0, 4, size=n).astype(np.uint8) for n in (1, 2, 9, 10, 11, 12, 31, 100, 999, 1000, 1001)]
+    reads += [np.tile(np.array([0, 1], np.uint8), 300), np.zeros(500, np.uint8), np.tile(np.array([3, 3, 0, 2, 2, 2], np.uint8), 1500)]
+    got = eng.process(reads)
+    for i, codes in enumerate(reads):
+        want = oracle.process(codes)
+        assert [tuple(r) for r in got[i]] == want, _diff_msg(i, want, [tuple(r) for r in got[i]])
+
+
+# ---- 3. full size: properties -----------------------------------------------------------------------------------
+def test_full_size_batch_independence_and_sample(eng, oracle):
+    reads = [c for _, c in synth.make_reads("headline2k", 10000, 2)]
+    eng.upload(reads)
+    eng.run()
+    full = eng.fetch()
+    cnt = eng.counters()
+    assert cnt["records"] == sum(len(r) for r in full)
+    # determinism: a second run of the same resident batch gives the same records
+    eng.run()
+    again = eng.fetch()
+    assert again == full
+    # batch independence: a sample processed alone, in reverse order, gives the same per-read records
+    rng = np.random.RandomState(99)
+    idx = rng.choice(len(reads), 96, replace=False)
+    sub = eng.process([reads[i] for i in idx[::-1]])
+    for k, i in enumerate(idx[::-1]):
+        assert sub[k] == full[i], f"read {i} depends on its batch"
+    # and the sample agrees with the oracle
+    for i in idx[:48]:
+        want = oracle.process(reads[i])
+        assert [tuple(r) for r in full[i]] == want, _diff_msg(i, want, [tuple(r) for r in full[i]])
+    # every record satisfies the reference's own acceptance gates (handle_one_read.c:139-146, :239-240)
+    for recs in full:
+        for r in recs:
+            tot = r.num_matches + r.num_mismatches + r.num_insertions + r.num_deletions
+            assert r.repeat_len > 0 and r.rep_start + 10 < r.rep_end
+            assert np.float32(r.num_matches) / np.float32(tot) >= np.float32(0.6)
+            assert r.num_freq_unit > 5 and 2 <= r.rep_period < 500 and len(r.unit) == r.rep_period
+            assert r.repeat_len == r.num_matches + r.num_mismatches + r.num_insertions
+
+
+# ---- error behaviour of the boundary -------------------------------------------------------------------------------
+def test_bad_arguments(eng):
+    with pytest.raises(mtr_amd.MtrError, match="MTR_ERR_BAD_ARG"):
+        eng.process([np.array([0, 1, 2, 4], np.uint8)])          # the reference exits on a non-ACGT character
+    with pytest.raises(mtr_amd.MtrError, match="MTR_ERR_BAD_ARG"):
+        eng.process([np.zeros(0, np.uint8)])
+    with pytest.raises(mtr_amd.MtrError, match="MTR_ERR_BAD_ARG"):
+        eng.process([])
+    # the context stays usable after an error
+    assert eng.process([np.tile(np.array([3, 3, 0, 2, 2, 2], np.uint8), 80)])[0]     # TTAGGG x 80

@@ -1,0 +1,90 @@
+/* fasta.c — batch FASTA reader keeping the reference's quirks (handle_one_file.c:169-269). */
+#include "mtr_host.h"
+#include <stdlib.h>
+#include <string.h>
+
+struct mtrh_fasta {
+    FILE *fp;
+    char  buf[MTRH_BLK];
+    char *pending_id;       /* header already consumed for the next record */
+    int   have_header, done;
+};
+
+static void *xrealloc(void *p, size_t n)
+{
+    void *q = realloc(p, n);
+    if (!q) { fprintf(stderr, "cannot allocate %zu bytes\n", n); exit(EXIT_FAILURE); }
+    return q;
+}
+
+static char *header_id(const char *line)
+{
+    size_t i = 1;
+    while (line[i] && line[i] != '\n' && line[i] != '\r') i++;
+    char *id = (char *)xrealloc(NULL, i);
+    memcpy(id, line + 1, i - 1);
+    id[i - 1] = 0;
+    return id;
+}
+
+mtrh_fasta *mtrh_fasta_open(const char *path)
+{
+    FILE *fp = fopen(path, "r");
+    if (!fp) { fprintf(stderr, "fatal error: cannot open %s\n", path); fflush(stderr); exit(EXIT_FAILURE); }
+    mtrh_fasta *f = (mtrh_fasta *)calloc(1, sizeof(*f));
+    f->fp = fp;
+    return f;
+}
+
+void mtrh_fasta_close(mtrh_fasta *f) { if (f) { fclose(f->fp); free(f->pending_id); free(f); } }
+void mtrh_read_free(mtrh_read *r) { free(r->id); free(r->codes); r->id = NULL; r->codes = NULL; r->len = 0; }
+
+/* one record; returns 0 at the end of input or at the first empty record (handle_one_file.c:283) */
+static int next_read(mtrh_fasta *f, mtrh_read *out)
+{
+    if (f->done) return 0;
+    uint8_t *codes = NULL; size_t n = 0, cap = 0;
+    char *id = f->pending_id; f->pending_id = NULL;
+    while (fgets(f->buf, MTRH_BLK, f->fp)) {
+        const char *s = f->buf;
+        if (s[0] == '>') {
+            if (!f->have_header) { f->have_header = 1; id = header_id(s); continue; }
+            f->pending_id = header_id(s);
+            if (n == 0) { f->done = 1; free(id); free(codes); return 0; }
+            out->id = id; out->codes = codes; out->len = (int32_t)n;
+            return 1;
+        }
+        for (size_t i = 0; s[i] && s[i] != '\n' && s[i] != '\r'; i++) {
+            uint8_t c;
+            switch (s[i]) {
+            case 'A': case 'a': c = 0; break;
+            case 'C': case 'c': c = 1; break;
+            case 'G': case 'g': c = 2; break;
+            case 'T': case 't': c = 3; break;
+            default: fprintf(stderr, "Invalid character: %c \n", s[i]); exit(EXIT_FAILURE);
+            }
+            if (n == cap) { cap = cap ? cap * 2 : 4096; codes = (uint8_t *)xrealloc(codes, cap); }
+            codes[n++] = c;
+            if (MTR_MAX_INPUT_LENGTH <= (int64_t)n) {
+                fprintf(stderr, "fatal error: The length %d is tentatively at most %i.\nread ID = %s\nSet MAX_INPUT_LENGTH to a larger value", (int)n, MTR_MAX_INPUT_LENGTH, id ? id : "");
+                exit(EXIT_FAILURE);
+            }
+        }
+    }
+    f->done = 1;
+    if (n == 0) { free(id); free(codes); return 0; }
+    if (!id) { id = (char *)xrealloc(NULL, 1); id[0] = 0; }
+    out->id = id; out->codes = codes; out->len = (int32_t)n;
+    return 1;
+}
+
+int mtrh_fasta_next_batch(mtrh_fasta *f, mtrh_read *out, int max_reads, int64_t max_bases)
+{
+    int n = 0; int64_t bases = 0;
+    while (n < max_reads && bases < max_bases) {
+        if (!next_read(f, &out[n])) break;
+        bases += out[n].len;
+        n++;
+    }
+    return n;
+}

@@ -1,0 +1,75 @@
+"""The C-ABI library on CPU: it builds for gfx950, loads, exports every symbol include/mtr_hip.h declares, keeps the
+record layout of the header, and refuses to run without a GPU (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import mtr_amd
+from mtr_amd import build as mbuild
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    mbuild.build()
+    return mtr_amd.load_library()
+
+
+def test_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "mtr_hip.h")).read()
+    declared = set(re.findall(r"\b(mtr_[a-z_0-9]+)\s*\(", hdr))
+    assert declared >= set(mtr_amd.EXPORTS)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/mtr_hip.h but not exported by libmtr_hip.so"
+    assert lib.mtr_abi_version() == 1
+
+
+def test_record_layout_matches_header():
+    assert C.sizeof(mtr_amd.CRecord) == 14 * 4 + 504 + 500 * 4 == 2560
+    assert mtr_amd.CRecord.unit.offset == 56 and mtr_amd.CRecord.unit_score.offset == 560
+
+
+def test_library_carries_gfx950_code_object():
+    data = open(mtr_amd.LIB_PATH, "rb").read()
+    assert b"gfx950" in data and b"mtr_k2_units" in data and b"mtr_k1_ranges" in data
+
+
+def test_no_cpu_fallback_without_device(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    assert lib.mtr_create(0, 1, C.c_float(0.6), C.byref(h)) == 1          # MTR_ERR_NO_DEVICE
+    assert not h.value
+    with pytest.raises(mtr_amd.MtrError, match="MTR_ERR_NO_DEVICE"):
+        mtr_amd.Engine()
+
+
+def test_product_does_not_reference_the_oracle():
+    """the product path may not import, link or call anything under oracle/ (it is the checker, not the product)"""
+    for base, _, files in os.walk(os.path.join(ROOT, "mtr_amd")):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", ".inc", "Makefile")):
+                txt = open(os.path.join(base, f), errors="replace").read()
+                assert "oracle/" not in txt and "mtr_oracle" not in txt and "liboracle" not in txt, os.path.join(base, f)
+
+
+def test_codes_from_str():
+    assert mtr_amd.codes_from_str("ACGTacgt").tolist() == [0, 1, 2, 3, 0, 1, 2, 3]
+    with pytest.raises(ValueError, match="Invalid character: N"):
+        mtr_amd.codes_from_str("ACNT")
+
+
+def test_synthetic_generator_is_seeded_and_shaped():
+    from mtr_amd import synth
+    a = synth.make_reads("c2", 5, 9)
+    b = synth.make_reads("c2", 5, 9)
+    assert all(np.array_equal(x[1], y[1]) for x, y in zip(a, b))
+    lens = [len(c) for _, c in synth.make_reads("headline2k", 50, 1)]
+    assert 1950 < np.mean(lens) < 2150                                 # unit 100 x 10 (+ins -del) + 2 x 500
+    mixed = [len(c) for _, c in synth.make_reads("c4", 50, 1)]
+    assert 1800 < np.mean(mixed) < 2400

@@ -1,0 +1,49 @@
+"""The drop-in command line on the GPU box: mtr_amd/host/mTR [-a] [-p] <fasta> must print byte for byte what the
+reference printed (tests/golden/*.stdout, isolated semantics) — FASTA in, report/alignment lines out."""
+import glob
+import os
+import subprocess
+
+import pytest
+
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "mtr_amd", "host")
+FLAGS = {"default": [], "p": ["-p"], "a": ["-a"]}
+
+
+@pytest.fixture(scope="module")
+def cli():
+    from mtr_amd import build as b
+    b.build()
+    subprocess.run(["make", "-s", "-C", HOST, "mTR"], check=True)
+    return os.path.join(HOST, "mTR")
+
+
+def _cases():
+    out = []
+    for p in sorted(glob.glob(os.path.join(gu.GOLDEN, "*.stdout"))):
+        name, mode, _ = os.path.basename(p).rsplit(".", 2)
+        out.append((name, mode))
+    return out
+
+
+@pytest.mark.parametrize("name,mode", _cases())
+def test_cli_stdout_matches_reference(cli, name, mode):
+    p = subprocess.run([cli, *FLAGS[mode], gu.input_path(name)], capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()[:500]
+    want = open(os.path.join(gu.GOLDEN, f"{name}.{mode}.stdout"), "rb").read()
+    assert p.stdout == want
+
+
+def test_cli_timing_block_and_errors(cli, tmp_path):
+    p = subprocess.run([cli, "-c", gu.input_path("3_5")], capture_output=True)
+    assert p.returncode == 0 and p.stderr.decode().startswith("Computation time\n") and "Count of queries" in p.stderr.decode()
+    bad = tmp_path / "bad.fa"
+    bad.write_text(">x\nACGTNACGT\n")
+    q = subprocess.run([cli, str(bad)], capture_output=True)
+    assert q.returncode != 0 and b"Invalid character: N" in q.stderr
+    r = subprocess.run([cli, "-m", "1.5", gu.input_path("3_5")], capture_output=True)
+    assert r.returncode != 0 and b"must range from 0 to 1" in r.stderr

@@ -20,7 +20,9 @@ STATUS = {0: "MTR_OK", 1: "MTR_ERR_NO_DEVICE", 2: "MTR_ERR_BAD_ARG", 3: "MTR_ERR
           5: "MTR_ERR_OVERFLOW", 6: "MTR_ERR_DP_TOO_LARGE"}
 COUNTER_NAMES = ["dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_dp_cells", "kmer_tables", "kmer_lookups",
                  "ranges_candidate", "ranges_executed", "records", "di_passes", "di_positions", "traceback_steps",
-                 "undefined_guards", "global_tables", "reserved"]
+                 "undefined_guards", "global_tables", "reserved",
+                 "cyc_total", "cyc_dp_fwd", "cyc_dp_tb", "cyc_tab_build", "cyc_seeds", "cyc_walk", "cyc_polish", "cyc_revise_vote",
+                 "cyc_slot_copy", "cyc_dp_fwd_rev", "cyc_dp_tb_rev"] + ["reserved%d" % i for i in range(27, 32)]
 EXPORTS = ["mtr_create", "mtr_destroy", "mtr_last_error", "mtr_abi_version", "mtr_process_batch", "mtr_free_results",
            "mtr_upload_batch", "mtr_run_resident", "mtr_fetch_results", "mtr_get_kernel_times", "mtr_get_counters",
            "mtr_test_ranges", "mtr_test_wrap_dp", "mtr_set_trace", "mtr_get_trace", "mtr_export_records_device"]
@@ -212,8 +214,8 @@ class Engine:
         return {"k1_ranges": float(kt[0].ms), "k2_units": float(kt[1].ms)}
 
     def counters(self):
-        c = (C.c_int64 * 16)()
-        self._check(self.lib.mtr_get_counters(self.h, c, 16), "mtr_get_counters")
+        c = (C.c_int64 * 32)()
+        self._check(self.lib.mtr_get_counters(self.h, c, 32), "mtr_get_counters")
         return {n: int(c[i]) for i, n in enumerate(COUNTER_NAMES)}
 
     # ---- building blocks (parity tests) ----------------------------------------------------------------------

@@ -166,6 +166,7 @@ extern "C" mtr_status mtr_upload_batch(mtr_ctx *ctx, const uint8_t *bases, const
         woff[(size_t)i] = words; words += lens[i] / 16 + 4;
         Lmax = std::max(Lmax, (int)lens[i]);
     }
+    words += 80;                                        // the DP stages 64-word blocks: keep the last block readable
     std::vector<uint32_t> packed((size_t)words, 0u);
     for (int i = 0; i < n; i++) {
         const uint8_t *b = bases + offsets[i]; uint32_t *w = packed.data() + woff[(size_t)i];
@@ -249,6 +250,7 @@ static mtr_status launch_k2(mtr_ctx *ctx)
     a.records = ctx->d_records; a.max_rec_per_read = ctx->max_rec; a.rec_count = ctx->d_reccount;
     a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
     a.trace = ctx->d_trace; a.trace_cap = ctx->trace_cap; a.trace_n = ctx->d_trace_n;
+    a.trace_mask = getenv("MTR_TRACE_MASK") ? (int32_t)strtol(getenv("MTR_TRACE_MASK"), nullptr, 0) : -1;
     HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_trace_n, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));

@@ -30,7 +30,10 @@ enum { DPC_Z = 0, DPC_M = 1, DPC_X = 2, DPC_DEL = 3, DPC_INS = 4, DPC_PENDING = 
 // device counters (index = MTR counters in include/mtr_hip.h)
 enum { CNT_DP_CALLS = 0, CNT_DP_CELLS, CNT_DP_ROWS, CNT_REV_CALLS, CNT_REV_CELLS, CNT_TABLES, CNT_LOOKUPS,
        CNT_RANGES_CAND, CNT_RANGES_EXEC, CNT_RECORDS, CNT_DI_PASSES, CNT_DI_POS, CNT_TB_STEPS, CNT_UNDEFINED,
-       CNT_GLOBAL_TABLES, CNT_N = 16 };
+       CNT_GLOBAL_TABLES, CNT_RESERVED15,
+       // shader-clock cycles per phase, summed over waves (profiling aid)
+       CYC_TOTAL = 16, CYC_DP_FWD, CYC_DP_TB, CYC_TAB_BUILD, CYC_SEEDS, CYC_WALK, CYC_POLISH, CYC_REVISE_VOTE, CYC_SLOT_COPY,
+       CYC_DP_FWD_REV, CYC_DP_TB_REV, CNT_N = 32 };
 
 // status word values written by the kernels (first error wins)
 enum { DEV_OK = 0, DEV_ERR_RANGE_OVERFLOW = 1, DEV_ERR_RECORD_OVERFLOW = 2, DEV_ERR_DP_TOO_LARGE = 3, DEV_ERR_INTERNAL = 4 };
@@ -156,7 +159,7 @@ struct K2Args {
     const int32_t *r_start; int32_t *r_end; const int32_t *r_w;    // r_end is overwritten (-1 = pruned)
     DevRecord *records; int32_t max_rec_per_read; int32_t *rec_count;
     int32_t *status; unsigned int *work_counter; unsigned long long *counters;
-    int32_t *trace; int32_t trace_cap; unsigned int *trace_n;
+    int32_t *trace; int32_t trace_cap; unsigned int *trace_n; int32_t trace_mask;   // bit t = record events of type t
 };
 
 struct DpTestArgs {

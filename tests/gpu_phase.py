@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Where K2's cycles go (development aid): phase timers summed over waves, for a single read and a batch."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mtr_amd
+from mtr_amd import synth
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+reads = [c for _, c in synth.make_reads("headline2k", n, 2)]
+eng = mtr_amd.Engine()
+for label, rs in (("single read", reads[:1]), (f"{n} reads", reads)):
+    eng.upload(rs); eng.run(); eng.run()
+    c = eng.counters(); kt = eng.kernel_times_ms()
+    tot = c["cyc_total"]
+    print(f"== {label}: K2 {kt['k2_units']:.1f} ms, K1 {kt['k1_ranges']:.1f} ms, total wave-cycles {tot/1e6:.1f} M (s_memtime ticks)")
+    for k in ("cyc_dp_fwd", "cyc_dp_tb", "cyc_dp_fwd_rev", "cyc_dp_tb_rev", "cyc_tab_build", "cyc_seeds", "cyc_walk", "cyc_polish", "cyc_revise_vote", "cyc_slot_copy"):
+        print(f"   {k:18s} {c[k]/1e6:10.1f} M  {100.0*c[k]/max(tot,1):5.1f} %")
+    rest = tot - sum(c[k] for k in c if k.startswith("cyc_") and k != "cyc_total")
+    print(f"   {'other':18s} {rest/1e6:10.1f} M  {100.0*rest/max(tot,1):5.1f} %")
+    print("   counts:", {k: c[k] for k in ("dp_calls", "dp_rows", "dp_cells", "traceback_steps", "kmer_tables", "kmer_lookups", "ranges_executed")})

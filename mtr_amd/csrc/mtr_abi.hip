@@ -241,7 +241,7 @@ static mtr_status launch_k2(mtr_ctx *ctx)
 {
     K2Layout y = k2_layout(ctx->Lmax);
     size_t total = 0;
-    int waves = pick_waves(ctx, ctx->n_reads, 6, y.total, &total);
+    int waves = pick_waves(ctx, ctx->n_reads, 16, y.total, &total);
     mtr_status s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;
     K2Args a;
     a.b = view(ctx); a.min_match_ratio = ctx->min_ratio; a.Lmax = ctx->Lmax;
@@ -269,7 +269,7 @@ extern "C" mtr_status mtr_run_resident(mtr_ctx *ctx)
     {
         K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
         size_t t1 = 0, t2 = 0;
-        (void)pick_waves(ctx, ctx->n_reads, 2, y1.total, &t1); (void)pick_waves(ctx, ctx->n_reads, 6, y2.total, &t2);
+        (void)pick_waves(ctx, ctx->n_reads, 2, y1.total, &t1); (void)pick_waves(ctx, ctx->n_reads, 16, y2.total, &t2);
         mtr_status s = ensure_scratch(ctx, std::max(t1, t2)); if (s != MTR_OK) return s;
     }
     HIPCHK(hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));

@@ -90,7 +90,8 @@ struct K2Layout {
     size_t score[K2_NSLOT];        // int32 [512]
     size_t cons, miss;             // int32 [501*5], [501*4]
     size_t pol_u, pol_rev;         // int32 [512] each (polish work arrays)
-    size_t gkeys, gvals;           // int32 [gcap] global-memory k-mer table for windows that do not fit LDS
+    size_t gkeys, gvals;           // int32 [gcap]: counts of the k-mer table (always) and keys of windows that do not fit LDS
+    size_t ties;                   // int32 [2][1024] tie lists of the look-ahead
     size_t total;
     size_t cells; unsigned gcap;
 };
@@ -106,7 +107,7 @@ static inline __host__ __device__ K2Layout k2_layout(int Lmax)
 {
     K2Layout y;
     y.cells = k2_max_cells(Lmax);
-    unsigned g = 64; while (g < 2u * (unsigned)(Lmax + 2)) g <<= 1;
+    unsigned g = 2048; while (g < 2u * (unsigned)(Lmax + 2)) g <<= 1;
     y.gcap = g;
     size_t o = 0;
     y.codes = o; o = mtrc_align(o + y.cells, 256);
@@ -116,6 +117,7 @@ static inline __host__ __device__ K2Layout k2_layout(int Lmax)
     y.miss = o; o = mtrc_align(o + 501 * 4 * 4, 16);
     y.pol_u = o; o = mtrc_align(o + 512 * 4, 16);
     y.pol_rev = o; o = mtrc_align(o + 1024 * 4, 16);   // also holds a revised unit (<= 2*499 bases)
+    y.ties = o; o = mtrc_align(o + 2 * MTRC_MAX_TIEBREAKS * 4, 16);
     y.gkeys = o; o = mtrc_align(o + (size_t)g * 4, 16);
     y.gvals = o; o = mtrc_align(o + (size_t)g * 4, 16);
     y.total = mtrc_align(o, 256);

@@ -222,7 +222,9 @@ static mtr_status launch_k1(mtr_ctx *ctx)
 {
     K1Layout y = k1_layout(ctx->Lmax);
     size_t total = 0;
-    int waves = pick_waves(ctx, ctx->n_reads, 2, y.total, &total);
+    const size_t lds = k1_hist_bytes(ctx->Lmax);
+    int per_cu = (int)((160u * 1024u) / lds); if (per_cu < 1) per_cu = 1; if (per_cu > 16) per_cu = 16;
+    int waves = pick_waves(ctx, ctx->n_reads, per_cu, y.total, &total);
     mtr_status s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;
     K1Args a;
     a.b = view(ctx); a.mt = ctx->d_mt; a.manhattan = ctx->manhattan; a.Lmax = ctx->Lmax;
@@ -231,7 +233,8 @@ static mtr_status launch_k1(mtr_ctx *ctx)
     a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
     HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL(mtr_k1_ranges, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a);
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&mtr_k1_ranges), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mtr_k1_ranges, dim3((unsigned)waves), dim3(64), (unsigned)lds, ctx->stream, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     return MTR_OK;
@@ -269,7 +272,7 @@ extern "C" mtr_status mtr_run_resident(mtr_ctx *ctx)
     {
         K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
         size_t t1 = 0, t2 = 0;
-        (void)pick_waves(ctx, ctx->n_reads, 2, y1.total, &t1); (void)pick_waves(ctx, ctx->n_reads, 16, y2.total, &t2);
+        (void)pick_waves(ctx, ctx->n_reads, 16, y1.total, &t1); (void)pick_waves(ctx, ctx->n_reads, 16, y2.total, &t2);
         mtr_status s = ensure_scratch(ctx, std::max(t1, t2)); if (s != MTR_OK) return s;
     }
     HIPCHK(hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));

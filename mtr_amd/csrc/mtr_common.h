@@ -33,7 +33,7 @@ enum { CNT_DP_CALLS = 0, CNT_DP_CELLS, CNT_DP_ROWS, CNT_REV_CALLS, CNT_REV_CELLS
        CNT_GLOBAL_TABLES, CNT_RESERVED15,
        // shader-clock cycles per phase, summed over waves (profiling aid)
        CYC_TOTAL = 16, CYC_DP_FWD, CYC_DP_TB, CYC_TAB_BUILD, CYC_SEEDS, CYC_WALK, CYC_POLISH, CYC_REVISE_VOTE, CYC_SLOT_COPY,
-       CYC_DP_FWD_REV, CYC_DP_TB_REV, CNT_N = 32 };
+       CYC_DP_FWD_REV, CYC_DP_TB_REV, CYC_K1_CODES, CYC_K1_PASSES, CYC_K1_EXTRACT, CYC_K1_DEDUP, CYC_K1_TOTAL, CNT_N = 32 };
 
 // status word values written by the kernels (first error wins)
 enum { DEV_OK = 0, DEV_ERR_RANGE_OVERFLOW = 1, DEV_ERR_RECORD_OVERFLOW = 2, DEV_ERR_DP_TOO_LARGE = 3, DEV_ERR_INTERNAL = 4 };
@@ -78,6 +78,18 @@ static inline __host__ __device__ K1Layout k1_layout(int Lmax)
     y.l_di = o;  o = mtrc_align(o + (size_t)y.cap * 8, 16);
     y.total = mtrc_align(o, 256);
     return y;
+}
+
+// bytes of LDS the K1 kernel needs for reads up to Lmax: 3*4^k uint16 counters per (k,w) pass
+// (passes: fill_directional_index.c:559-582)
+static inline __host__ __device__ size_t k1_hist_bytes(int Lmax)
+{
+    size_t n = 0;
+    for (int k = 1; k <= 5; k += 2) {
+        int max_w = (k == 1) ? 20 : (k == 3 ? 80 : MTRC_MAX_WINDOW);
+        for (int w = MTRC_MIN_WINDOW; w <= max_w && w < Lmax / 2; w *= 2) n += 3u * (1u << (2 * k));
+    }
+    return mtrc_align(n * 2 + 64, 256);
 }
 
 // ---- K2 per-wave scratch layout ------------------------------------------------------------------

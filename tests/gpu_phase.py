@@ -14,6 +14,8 @@ for label, rs in (("single read", reads[:1]), (f"{n} reads", reads)):
     print(f"== {label}: K2 {kt['k2_units']:.1f} ms, K1 {kt['k1_ranges']:.1f} ms, total wave-cycles {tot/1e6:.1f} M (s_memtime ticks)")
     for k in ("cyc_dp_fwd", "cyc_dp_tb", "cyc_dp_fwd_rev", "cyc_dp_tb_rev", "cyc_tab_build", "cyc_seeds", "cyc_walk", "cyc_polish", "cyc_revise_vote", "cyc_slot_copy"):
         print(f"   {k:18s} {c[k]/1e6:10.1f} M  {100.0*c[k]/max(tot,1):5.1f} %")
-    rest = tot - sum(c[k] for k in c if k.startswith("cyc_") and k != "cyc_total")
+    k1 = c["cyc_k1_total"]
+    print(f"   K1 wave-cycles {k1/1e6:.1f} M: codes {100*c['cyc_k1_codes']/max(k1,1):.1f} %  passes {100*c['cyc_k1_passes']/max(k1,1):.1f} %  extract {100*c['cyc_k1_extract']/max(k1,1):.1f} %  dedup+out {100*c['cyc_k1_dedup']/max(k1,1):.1f} %")
+    rest = tot - sum(c[k] for k in c if k.startswith("cyc_") and k != "cyc_total" and not k.startswith("cyc_k1"))
     print(f"   {'other':18s} {rest/1e6:10.1f} M  {100.0*rest/max(tot,1):5.1f} %")
     print("   counts:", {k: c[k] for k in ("dp_calls", "dp_rows", "dp_cells", "traceback_steps", "kmer_tables", "kmer_lookups", "ranges_executed")})

@@ -244,7 +244,9 @@ static mtr_status launch_k2(mtr_ctx *ctx)
 {
     K2Layout y = k2_layout(ctx->Lmax);
     size_t total = 0;
-    int waves = pick_waves(ctx, ctx->n_reads, 16, y.total, &total);
+    int k2_per_cu = getenv("MTR_K2_WAVES_PER_CU") ? atoi(getenv("MTR_K2_WAVES_PER_CU")) : 16;   // tuning knob (default: LDS/VGPR limit)
+    if (k2_per_cu < 1) k2_per_cu = 1; if (k2_per_cu > 16) k2_per_cu = 16;
+    int waves = pick_waves(ctx, ctx->n_reads, k2_per_cu, y.total, &total);
     mtr_status s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;
     K2Args a;
     a.b = view(ctx); a.min_match_ratio = ctx->min_ratio; a.Lmax = ctx->Lmax;

@@ -13,7 +13,7 @@ from typing import List, NamedTuple, Sequence
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmtr_hip.so")
+LIB_PATH = os.environ.get("MTR_LIB", os.path.join(HERE, "libmtr_hip.so"))   # MTR_LIB: A/B another build of the library
 MAX_PERIOD = 500
 
 STATUS = {0: "MTR_OK", 1: "MTR_ERR_NO_DEVICE", 2: "MTR_ERR_BAD_ARG", 3: "MTR_ERR_OOM", 4: "MTR_ERR_HIP",

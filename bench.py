@@ -102,37 +102,50 @@ def main():
 
     # every rank owns its own block of reads (weak scaling): same distribution, different seed
     reads = [c for _, c in synth.make_reads(WORKLOAD, a.reads, seed=2 + rank)]
-    eng = mtr_amd.Engine(device=local_rank)
-    eng.upload(reads)                                   # inputs resident in HBM before the timed region
+    # Two contexts (own stream, own result and scratch buffers) hold the same resident batch: consecutive steps
+    # alternate between them, so the kernels of step s+1 are enqueued while the last wavefronts of step s are
+    # still finishing (a read is one wavefront's serial chain, the slowest read of a batch takes ~3x the mean).
+    # Every step still does all of its work; only the barrier between steps is gone, as in a real multi-batch run.
+    engs = [mtr_amd.Engine(device=local_rank), mtr_amd.Engine(device=local_rank)]
+    for e in engs:
+        e.upload(reads)                                 # inputs resident in HBM before the timed region
+    eng = engs[0]
 
-    rec_buf = None
+    rec_buf = [None, None]
 
-    def step():
-        nonlocal rec_buf
-        eng.run()
+    def finish(s):
+        e = engs[s % 2]
+        e.wait()
         if world > 1:
             # exchange step: gather the per-read record tables to rank 0 over RCCL
-            total = eng.counters()["records"]
-            if rec_buf is None or rec_buf.numel() < total * RECORD_BYTES:
-                rec_buf = torch.empty(max(total, 1) * RECORD_BYTES * 5 // 4, dtype=torch.uint8, device="cuda")
-            counts, tot = eng.export_records_device(rec_buf.data_ptr(), rec_buf.numel() // RECORD_BYTES)
-            gather_records(rec_buf[: tot * RECORD_BYTES], torch.from_numpy(counts).cuda(), dst=0)
+            total = e.counters()["records"]
+            rb = rec_buf[s % 2]
+            if rb is None or rb.numel() < total * RECORD_BYTES:
+                rb = rec_buf[s % 2] = torch.empty(max(total, 1) * RECORD_BYTES * 5 // 4, dtype=torch.uint8, device="cuda")
+            counts, tot = e.export_records_device(rb.data_ptr(), rb.numel() // RECORD_BYTES)
+            gather_records(rb[: tot * RECORD_BYTES], torch.from_numpy(counts).cuda(), dst=0)
+        return e.kernel_times_ms()
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
+    sync_k1, sync_k2 = [], []
+    for w in range(a.warmup):                           # warm-up steps run one at a time (un-overlapped kernel times)
+        engs[w % 2].run_async()
+        kt = finish(w)
+        sync_k1.append(kt["k1_ranges"]); sync_k2.append(kt["k2_units"])
     k2_ms, k1_ms = [], []
     sync()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-        kt = eng.kernel_times_ms()
-        k1_ms.append(kt["k1_ranges"])
-        k2_ms.append(kt["k2_units"])
+    engs[0].run_async()
+    for s in range(1, a.steps):
+        engs[s % 2].run_async()
+        kt = finish(s - 1)
+        k1_ms.append(kt["k1_ranges"]); k2_ms.append(kt["k2_units"])
+    kt = finish(a.steps - 1)
+    k1_ms.append(kt["k1_ranges"]); k2_ms.append(kt["k2_units"])
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -169,10 +182,12 @@ def main():
                                    f"mean L {np.mean([len(r) for r in reads]):.0f}, error profile sub 1.6/ins 9.0/del 3.8 %",
                        "reads_per_gpu": n_local, "parallelism": f"reads sharded over {world} GPU(s), gather to rank 0"},
             "ms_per_read": dt / a.steps * 1e3 / n_local,
-            "kernels_ms": {"k1_ranges": float(np.mean(k1_ms)), "k2_units": float(np.mean(k2_ms))},
+            "kernels_ms": {"k1_ranges": float(np.mean(k1_ms)), "k2_units": float(np.mean(k2_ms)),
+                           "note": "HIP-event durations over the timed region; consecutive steps overlap on the GPU, so a launch shares the chip with its neighbour"},
+            "kernels_ms_alone": {"k1_ranges": float(np.mean(sync_k1)) if sync_k1 else None, "k2_units": float(np.mean(sync_k2)) if sync_k2 else None},
             "work_per_launch": {k: cnt[k] for k in ("dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_dp_cells",
                                                     "kmer_tables", "kmer_lookups", "ranges_executed", "records", "traceback_steps")},
-            "roofline": {"bound": "hbm", "kernel": "mtr_k2_units", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "mtr_k_reads", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "algorithmic_bytes_per_launch": b_alg,
                          "valu": {"achieved_lane_ops_per_s": valu_ops, "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
@@ -192,7 +207,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(reads, a.cpu_sample)
             out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    eng.close()
+    for e in engs:
+        e.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

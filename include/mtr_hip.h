@@ -93,6 +93,11 @@ void       mtr_free_results(mtr_record *records, int32_t *counts);
  * kernels on the context's stream and returns after they finish; fetch copies the records back. */
 mtr_status mtr_upload_batch(mtr_ctx *ctx, const uint8_t *bases, const int64_t *offsets, const int32_t *lens, int32_t n_reads);
 mtr_status mtr_run_resident(mtr_ctx *ctx);
+/* The run split in two: _async enqueues the kernels on the context's stream and returns; mtr_wait blocks until
+ * they finish and collects status, kernel times and counters.  Two contexts on one GPU can so overlap the tail of
+ * one batch with the start of the next (bench.py pipelines its steps this way). */
+mtr_status mtr_run_resident_async(mtr_ctx *ctx);
+mtr_status mtr_wait(mtr_ctx *ctx);
 mtr_status mtr_fetch_results(mtr_ctx *ctx, mtr_record **out_records, int32_t **out_counts, int64_t *out_total);
 
 /* Multi-GPU plumbing: compacts the records of the last run (read after read, insertion order) into

@@ -26,7 +26,8 @@ COUNTER_NAMES = ["dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_d
                  "cyc_k1_dedup", "cyc_k1_total"]
 EXPORTS = ["mtr_create", "mtr_destroy", "mtr_last_error", "mtr_abi_version", "mtr_process_batch", "mtr_free_results",
            "mtr_upload_batch", "mtr_run_resident", "mtr_fetch_results", "mtr_get_kernel_times", "mtr_get_counters",
-           "mtr_test_ranges", "mtr_test_wrap_dp", "mtr_set_trace", "mtr_get_trace", "mtr_export_records_device"]
+           "mtr_test_ranges", "mtr_test_wrap_dp", "mtr_set_trace", "mtr_get_trace", "mtr_export_records_device",
+           "mtr_run_resident_async", "mtr_wait"]
 
 
 class MtrError(RuntimeError):
@@ -91,6 +92,10 @@ def load_library(path: str = LIB_PATH):
     lib.mtr_upload_batch.restype = C.c_int
     lib.mtr_run_resident.argtypes = [C.c_void_p]
     lib.mtr_run_resident.restype = C.c_int
+    lib.mtr_run_resident_async.argtypes = [C.c_void_p]
+    lib.mtr_run_resident_async.restype = C.c_int
+    lib.mtr_wait.argtypes = [C.c_void_p]
+    lib.mtr_wait.restype = C.c_int
     lib.mtr_fetch_results.argtypes = [C.c_void_p, P(P(CRecord)), P(P(C.c_int32)), P(C.c_int64)]
     lib.mtr_fetch_results.restype = C.c_int
     lib.mtr_get_kernel_times.argtypes = [C.c_void_p, P(CKernelTime), C.c_int32]
@@ -160,6 +165,13 @@ class Engine:
 
     def run(self):
         self._check(self.lib.mtr_run_resident(self.h), "mtr_run_resident")
+
+    def run_async(self):
+        """enqueue K1 + K2 on the context's stream without waiting (mtr_run_resident_async)"""
+        self._check(self.lib.mtr_run_resident_async(self.h), "mtr_run_resident_async")
+
+    def wait(self):
+        self._check(self.lib.mtr_wait(self.h), "mtr_wait")
 
     def fetch(self) -> List[List[Record]]:
         recs = C.POINTER(CRecord)()

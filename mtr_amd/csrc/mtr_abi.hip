@@ -61,12 +61,13 @@ struct mtr_ctx {
     int64_t *d_roff = nullptr; int32_t *d_rcount = nullptr, *d_rstart = nullptr, *d_rend = nullptr, *d_rw = nullptr; uint64_t *d_rdi = nullptr;
     int64_t total_rcap = 0;
     DevRecord *d_records = nullptr; int32_t *d_reccount = nullptr; int max_rec = 0;
+    int64_t *d_recoff = nullptr;     // [n_reads+1] exclusive prefix of the record counts (compaction)
     int32_t *d_status = nullptr; unsigned int *d_work = nullptr; unsigned long long *d_counters = nullptr;
     uint8_t *d_scratch = nullptr; size_t scratch_bytes = 0;
     int32_t *d_trace = nullptr; unsigned *d_trace_n = nullptr; int trace_cap = 0;
     mtr_kernel_time kt[2] = { { 0, 0 }, { 0, 0 } };
     unsigned long long counters[CNT_N] = { 0 };
-    bool ran = false;
+    bool ran = false, pending = false;
 };
 
 static bool dbg() { static int v = -1; if (v < 0) v = getenv("MTR_DEBUG") ? 1 : 0; return v == 1; }
@@ -75,13 +76,22 @@ static bool dbg() { static int v = -1; if (v < 0) v = getenv("MTR_DEBUG") ? 1 : 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return MTR_ERR_HIP; } } while (0)
 
+// Blocking copy on the context's own stream.  The stream is created non-blocking and nothing on the run path
+// touches the null stream, so two contexts on one device overlap their kernels (a null-stream hipMemcpy would
+// wait for every other context's work).
+static hipError_t copy_sync(mtr_ctx *ctx, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, ctx->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream);
+}
+
 template <typename T> static void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
 static void free_batch(mtr_ctx *ctx)
 {
     dfree(ctx->d_packed); dfree(ctx->d_woff); dfree(ctx->d_lens); dfree(ctx->d_order);
     dfree(ctx->d_roff); dfree(ctx->d_rcount); dfree(ctx->d_rstart); dfree(ctx->d_rend); dfree(ctx->d_rw); dfree(ctx->d_rdi);
-    dfree(ctx->d_records); dfree(ctx->d_reccount);
+    dfree(ctx->d_records); dfree(ctx->d_reccount); dfree(ctx->d_recoff);
     ctx->n_reads = 0; ctx->ran = false;
 }
 
@@ -101,7 +111,7 @@ extern "C" mtr_status mtr_create(int device, int manhattan, float min_match_rati
     ctx->device = device; ctx->manhattan = manhattan ? 1 : 0; ctx->min_ratio = min_match_ratio;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
-    bool ok = hipStreamCreate(&ctx->stream) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 4; i++) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
     ok = ok && hipMalloc(&ctx->d_status, sizeof(int32_t)) == hipSuccess;
     ok = ok && hipMalloc(&ctx->d_work, sizeof(unsigned)) == hipSuccess;
@@ -111,7 +121,7 @@ extern "C" mtr_status mtr_create(int device, int manhattan, float min_match_rati
         // the read-independent MT19937 base stream: first min(L+4r,1e6) draws + two flanks of r <= 1e5
         std::vector<uint8_t> mt;
         mt_bases(mt, (size_t)MTRC_MAX_INPUT_LENGTH + 2 * 100000 + 64);
-        ok = hipMalloc(&ctx->d_mt, mt.size()) == hipSuccess && hipMemcpy(ctx->d_mt, mt.data(), mt.size(), hipMemcpyHostToDevice) == hipSuccess;
+        ok = hipMalloc(&ctx->d_mt, mt.size()) == hipSuccess && copy_sync(ctx, ctx->d_mt, mt.data(), mt.size(), hipMemcpyHostToDevice) == hipSuccess;
     }
     if (!ok) { mtr_destroy(ctx); return MTR_ERR_NO_DEVICE; }
     *out = ctx;
@@ -158,6 +168,7 @@ extern "C" mtr_status mtr_upload_batch(mtr_ctx *ctx, const uint8_t *bases, const
     if (!ctx) return MTR_ERR_BAD_ARG;
     if (!bases || !offsets || !lens || n <= 0) { ctx->err = "null input or n_reads <= 0"; return MTR_ERR_BAD_ARG; }
     HIPCHK(hipSetDevice(ctx->device));
+    { mtr_status w = mtr_wait(ctx); if (w != MTR_OK && w != MTR_ERR_OVERFLOW && w != MTR_ERR_DP_TOO_LARGE) return w; }
     free_batch(ctx);
     std::vector<int64_t> woff((size_t)n);
     int64_t words = 0; int Lmax = 0;
@@ -190,6 +201,7 @@ extern "C" mtr_status mtr_upload_batch(mtr_ctx *ctx, const uint8_t *bases, const
     HIPCHK(hipMalloc(&ctx->d_rw, (size_t)ctx->total_rcap * 4)); HIPCHK(hipMalloc(&ctx->d_rdi, (size_t)ctx->total_rcap * 8));
     HIPCHK(hipMalloc(&ctx->d_records, (size_t)n * (size_t)ctx->max_rec * sizeof(DevRecord)));
     HIPCHK(hipMalloc(&ctx->d_reccount, (size_t)n * 4));
+    HIPCHK(hipMalloc(&ctx->d_recoff, ((size_t)n + 1) * 8));
     HIPCHK(hipMemcpyAsync(ctx->d_packed, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_woff, woff.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_lens, lens, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -208,7 +220,7 @@ static BatchView view(const mtr_ctx *ctx)
 static mtr_status check_status(mtr_ctx *ctx)
 {
     int32_t st = 0;
-    HIPCHK(hipMemcpy(&st, ctx->d_status, 4, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(ctx, &st, ctx->d_status, 4, hipMemcpyDeviceToHost));
     switch (st) {
     case DEV_OK: return MTR_OK;
     case DEV_ERR_RANGE_OVERFLOW: ctx->err = "a read produced more candidate ranges than L/2+64"; return MTR_ERR_OVERFLOW;
@@ -218,39 +230,48 @@ static mtr_status check_status(mtr_ctx *ctx)
     }
 }
 
+static int waves_per_cu()
+{   // 16 = the LDS / VGPR limit of both kernels; MTR_K2_WAVES_PER_CU is a tuning knob
+    int v = getenv("MTR_K2_WAVES_PER_CU") ? atoi(getenv("MTR_K2_WAVES_PER_CU")) : 16;
+    return v < 1 ? 1 : (v > 16 ? 16 : v);
+}
+
+static void k1_args(mtr_ctx *ctx, K1Args &a, size_t per_wave)
+{
+    a.b = view(ctx); a.mt = ctx->d_mt; a.manhattan = ctx->manhattan; a.Lmax = ctx->Lmax;
+    a.scratch = ctx->d_scratch; a.scratch_per_wave = per_wave;
+    a.r_count = ctx->d_rcount; a.r_off = ctx->d_roff; a.r_start = ctx->d_rstart; a.r_end = ctx->d_rend; a.r_w = ctx->d_rw; a.r_di = ctx->d_rdi;
+    a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
+}
+
+// K1 alone (mtr_test_ranges)
 static mtr_status launch_k1(mtr_ctx *ctx)
 {
     K1Layout y = k1_layout(ctx->Lmax);
     size_t total = 0;
-    const size_t lds = k1_hist_bytes(ctx->Lmax);
-    int per_cu = (int)((160u * 1024u) / lds); if (per_cu < 1) per_cu = 1; if (per_cu > 16) per_cu = 16;
-    int waves = pick_waves(ctx, ctx->n_reads, per_cu, y.total, &total);
+    int waves = pick_waves(ctx, ctx->n_reads, waves_per_cu(), y.total, &total);
     mtr_status s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;
-    K1Args a;
-    a.b = view(ctx); a.mt = ctx->d_mt; a.manhattan = ctx->manhattan; a.Lmax = ctx->Lmax;
-    a.scratch = ctx->d_scratch; a.scratch_per_wave = y.total;
-    a.r_count = ctx->d_rcount; a.r_off = ctx->d_roff; a.r_start = ctx->d_rstart; a.r_end = ctx->d_rend; a.r_w = ctx->d_rw; a.r_di = ctx->d_rdi;
-    a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
+    K1Args a; k1_args(ctx, a, y.total);
     HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&mtr_k1_ranges), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(mtr_k1_ranges, dim3((unsigned)waves), dim3(64), (unsigned)lds, ctx->stream, a);
+    hipLaunchKernelGGL(mtr_k1_ranges, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     return MTR_OK;
 }
 
-static mtr_status launch_k2(mtr_ctx *ctx)
+// the per-read kernel: ranges (K1 code) and unit search / DP (K2 code) of a read by the same wavefront
+static mtr_status launch_reads(mtr_ctx *ctx)
 {
-    K2Layout y = k2_layout(ctx->Lmax);
+    K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
+    const size_t per_wave = std::max(y1.total, y2.total);       // the two phases of a read use the arena one after the other
     size_t total = 0;
-    int k2_per_cu = getenv("MTR_K2_WAVES_PER_CU") ? atoi(getenv("MTR_K2_WAVES_PER_CU")) : 16;   // tuning knob (default: LDS/VGPR limit)
-    if (k2_per_cu < 1) k2_per_cu = 1; if (k2_per_cu > 16) k2_per_cu = 16;
-    int waves = pick_waves(ctx, ctx->n_reads, k2_per_cu, y.total, &total);
+    int waves = pick_waves(ctx, ctx->n_reads, waves_per_cu(), per_wave, &total);
     mtr_status s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;
+    K1Args a1; k1_args(ctx, a1, per_wave);
     K2Args a;
     a.b = view(ctx); a.min_match_ratio = ctx->min_ratio; a.Lmax = ctx->Lmax;
-    a.scratch = ctx->d_scratch; a.scratch_per_wave = y.total;
+    a.scratch = ctx->d_scratch; a.scratch_per_wave = per_wave;
     a.r_count = ctx->d_rcount; a.r_off = ctx->d_roff; a.r_start = ctx->d_rstart; a.r_end = ctx->d_rend; a.r_w = ctx->d_rw;
     a.records = ctx->d_records; a.max_rec_per_read = ctx->max_rec; a.rec_count = ctx->d_reccount;
     a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
@@ -259,35 +280,45 @@ static mtr_status launch_k2(mtr_ctx *ctx)
     HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_trace_n, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
-    hipLaunchKernelGGL(mtr_k2_units, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a);
+    if (ctx->manhattan) hipLaunchKernelGGL(mtr_k_reads<true>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a1, a);
+    else hipLaunchKernelGGL(mtr_k_reads<false>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a1, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
     return MTR_OK;
 }
 
-extern "C" mtr_status mtr_run_resident(mtr_ctx *ctx)
+extern "C" mtr_status mtr_run_resident_async(mtr_ctx *ctx)
 {
     if (!ctx) return MTR_ERR_BAD_ARG;
     if (ctx->n_reads <= 0) { ctx->err = "no batch uploaded"; return MTR_ERR_BAD_ARG; }
     HIPCHK(hipSetDevice(ctx->device));
-    // both kernels share one scratch arena: size it for the larger user before anything is launched
-    {
-        K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
-        size_t t1 = 0, t2 = 0;
-        (void)pick_waves(ctx, ctx->n_reads, 16, y1.total, &t1); (void)pick_waves(ctx, ctx->n_reads, 16, y2.total, &t2);
-        mtr_status s = ensure_scratch(ctx, std::max(t1, t2)); if (s != MTR_OK) return s;
-    }
+    { mtr_status w = mtr_wait(ctx); if (w != MTR_OK) return w; }
     HIPCHK(hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
-    mtr_status s = launch_k1(ctx); if (s != MTR_OK) return s;
-    s = launch_k2(ctx); if (s != MTR_OK) return s;
+    mtr_status s = launch_reads(ctx); if (s != MTR_OK) return s;
+    ctx->pending = true;
+    return MTR_OK;
+}
+
+extern "C" mtr_status mtr_wait(mtr_ctx *ctx)
+{
+    if (!ctx) return MTR_ERR_BAD_ARG;
+    if (!ctx->pending) return MTR_OK;
+    HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->pending = false;
     float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->kt[0].ms = ms; ctx->kt[0].launches = 1;
+    ctx->kt[0].ms = 0; ctx->kt[0].launches = 0;                // K1 runs inside the per-read kernel
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->kt[1].ms = ms; ctx->kt[1].launches = 1;
-    HIPCHK(hipMemcpy(ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(ctx, ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
     ctx->ran = true;
     return check_status(ctx);
+}
+
+extern "C" mtr_status mtr_run_resident(mtr_ctx *ctx)
+{
+    mtr_status s = mtr_run_resident_async(ctx); if (s != MTR_OK) return s;
+    return mtr_wait(ctx);
 }
 
 __global__ void mtr_k_compact(const DevRecord *in, const int32_t *cnt, const int64_t *off, int max_rec, int n_reads, DevRecord *out)
@@ -305,27 +336,27 @@ __global__ void mtr_k_compact(const DevRecord *in, const int32_t *cnt, const int
 extern "C" mtr_status mtr_fetch_results(mtr_ctx *ctx, mtr_record **out_records, int32_t **out_counts, int64_t *out_total)
 {
     if (!ctx || !out_records || !out_counts) return MTR_ERR_BAD_ARG;
+    { mtr_status w = mtr_wait(ctx); if (w != MTR_OK) return w; }
     if (!ctx->ran) { ctx->err = "nothing has been run"; return MTR_ERR_BAD_ARG; }
     HIPCHK(hipSetDevice(ctx->device));
     const int n = ctx->n_reads;
     int32_t *counts = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
     if (!counts) return MTR_ERR_OOM;
-    HIPCHK(hipMemcpy(counts, ctx->d_reccount, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(ctx, counts, ctx->d_reccount, (size_t)n * 4, hipMemcpyDeviceToHost));
     std::vector<int64_t> off((size_t)n + 1, 0);
     for (int i = 0; i < n; i++) off[(size_t)i + 1] = off[(size_t)i] + counts[i];
     const int64_t total = off[(size_t)n];
     mtr_record *recs = (mtr_record *)malloc(sizeof(mtr_record) * (size_t)std::max<int64_t>(total, 1));
     if (!recs) { free(counts); return MTR_ERR_OOM; }
     if (total > 0) {
-        DevRecord *d_out = nullptr; int64_t *d_off = nullptr;
+        DevRecord *d_out = nullptr; int64_t *d_off = ctx->d_recoff;
         HIPCHK(hipMalloc(&d_out, (size_t)total * sizeof(DevRecord)));
-        HIPCHK(hipMalloc(&d_off, ((size_t)n + 1) * 8));
         HIPCHK(hipMemcpyAsync(d_off, off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(mtr_k_compact, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->d_records, ctx->d_reccount, d_off, ctx->max_rec, n, d_out);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(recs, d_out, (size_t)total * sizeof(DevRecord), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(d_out); (void)hipFree(d_off);
+        (void)hipFree(d_out);
     }
     *out_records = recs; *out_counts = counts; if (out_total) *out_total = total;
     return MTR_OK;
@@ -336,22 +367,21 @@ extern "C" mtr_status mtr_fetch_results(mtr_ctx *ctx, mtr_record **out_records, 
 extern "C" mtr_status mtr_export_records_device(mtr_ctx *ctx, void *d_dst, int64_t capacity_records, int32_t *counts_host, int64_t *out_total)
 {
     if (!ctx || !counts_host || !out_total) return MTR_ERR_BAD_ARG;
+    { mtr_status w = mtr_wait(ctx); if (w != MTR_OK) return w; }
     if (!ctx->ran) { ctx->err = "nothing has been run"; return MTR_ERR_BAD_ARG; }
     HIPCHK(hipSetDevice(ctx->device));
     const int n = ctx->n_reads;
-    HIPCHK(hipMemcpy(counts_host, ctx->d_reccount, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(ctx, counts_host, ctx->d_reccount, (size_t)n * 4, hipMemcpyDeviceToHost));
     std::vector<int64_t> off((size_t)n + 1, 0);
     for (int i = 0; i < n; i++) off[(size_t)i + 1] = off[(size_t)i] + counts_host[i];
     *out_total = off[(size_t)n];
     if (off[(size_t)n] == 0) return MTR_OK;
     if (!d_dst || off[(size_t)n] > capacity_records) { ctx->err = "destination holds " + std::to_string(capacity_records) + " records, " + std::to_string(off[(size_t)n]) + " needed"; return MTR_ERR_OVERFLOW; }
-    int64_t *d_off = nullptr;
-    HIPCHK(hipMalloc(&d_off, ((size_t)n + 1) * 8));
+    int64_t *d_off = ctx->d_recoff;
     HIPCHK(hipMemcpyAsync(d_off, off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(mtr_k_compact, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->d_records, ctx->d_reccount, d_off, ctx->max_rec, n, (DevRecord *)d_dst);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d_off);
     return MTR_OK;
 }
 
@@ -394,11 +424,11 @@ extern "C" mtr_status mtr_test_ranges(mtr_ctx *ctx, int32_t **out_counts, int32_
     const int n = ctx->n_reads;
     std::vector<int32_t> cnt((size_t)n), st((size_t)ctx->total_rcap), en((size_t)ctx->total_rcap), ww((size_t)ctx->total_rcap);
     std::vector<uint64_t> di((size_t)ctx->total_rcap);
-    HIPCHK(hipMemcpy(cnt.data(), ctx->d_rcount, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(st.data(), ctx->d_rstart, st.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(en.data(), ctx->d_rend, en.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ww.data(), ctx->d_rw, ww.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(di.data(), ctx->d_rdi, di.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(ctx, cnt.data(), ctx->d_rcount, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(ctx, st.data(), ctx->d_rstart, st.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(ctx, en.data(), ctx->d_rend, en.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(ctx, ww.data(), ctx->d_rw, ww.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(ctx, di.data(), ctx->d_rdi, di.size() * 8, hipMemcpyDeviceToHost));
     int64_t total = 0; for (int i = 0; i < n; i++) total += cnt[(size_t)i];
     int32_t *oc = (int32_t *)malloc((size_t)n * 4), *os = (int32_t *)malloc((size_t)std::max<int64_t>(total, 1) * 4);
     int32_t *oe = (int32_t *)malloc((size_t)std::max<int64_t>(total, 1) * 4), *ow = (int32_t *)malloc((size_t)std::max<int64_t>(total, 1) * 4);
@@ -438,10 +468,10 @@ extern "C" mtr_status mtr_test_wrap_dp(mtr_ctx *ctx, int32_t n_tasks, const int3
     const size_t nt = (size_t)n_tasks;
     HIPCHK(hipMalloc(&d_i32, (nt * 7 + 1) * 4)); HIPCHK(hipMalloc(&d_units, (size_t)unit_off[n_tasks] + 16)); HIPCHK(hipMalloc(&d_out, nt * 8 * 4));
     int32_t *d_rd = d_i32, *d_qs = d_i32 + nt, *d_qe = d_i32 + 2 * nt, *d_g = d_i32 + 3 * nt, *d_m = d_i32 + 4 * nt, *d_d = d_i32 + 5 * nt, *d_uo = d_i32 + 6 * nt;
-    HIPCHK(hipMemcpy(d_rd, read_idx, nt * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_qs, query_start, nt * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_qe, query_end, nt * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_g, gain, nt * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_m, mismatch, nt * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_d, indel, nt * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_uo, unit_off, (nt + 1) * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_units, units, (size_t)unit_off[n_tasks], hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(ctx, d_rd, read_idx, nt * 4, hipMemcpyHostToDevice)); HIPCHK(copy_sync(ctx, d_qs, query_start, nt * 4, hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(ctx, d_qe, query_end, nt * 4, hipMemcpyHostToDevice)); HIPCHK(copy_sync(ctx, d_g, gain, nt * 4, hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(ctx, d_m, mismatch, nt * 4, hipMemcpyHostToDevice)); HIPCHK(copy_sync(ctx, d_d, indel, nt * 4, hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(ctx, d_uo, unit_off, (nt + 1) * 4, hipMemcpyHostToDevice)); HIPCHK(copy_sync(ctx, d_units, units, (size_t)unit_off[n_tasks], hipMemcpyHostToDevice));
     DpTestArgs a;
     a.b = view(ctx); a.n_tasks = n_tasks; a.read_idx = d_rd; a.qs = d_qs; a.qe = d_qe; a.units = d_units; a.unit_off = d_uo;
     a.gain = d_g; a.mism = d_m; a.indel = d_d; a.out8 = d_out; a.scratch = ctx->d_scratch; a.scratch_per_wave = per_wave; a.cells_cap = cells;
@@ -457,8 +487,8 @@ extern "C" mtr_status mtr_test_wrap_dp(mtr_ctx *ctx, int32_t n_tasks, const int3
     HIPCHK(hipStreamSynchronize(ctx->stream));
     DBG("test_wrap_dp: kernel done");
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->kt[1].ms = ms; ctx->kt[1].launches = 1;
-    HIPCHK(hipMemcpy(ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(out8, d_out, nt * 8 * 4, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(ctx, ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(ctx, out8, d_out, nt * 8 * 4, hipMemcpyDeviceToHost));
     (void)hipFree(d_i32); (void)hipFree(d_units); (void)hipFree(d_out);
     return check_status(ctx);
 }
@@ -477,11 +507,11 @@ extern "C" mtr_status mtr_get_trace(mtr_ctx *ctx, int32_t **out_events, int64_t 
     if (!ctx || !out_events || !out_n) return MTR_ERR_BAD_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     unsigned n = 0;
-    HIPCHK(hipMemcpy(&n, ctx->d_trace_n, 4, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(ctx, &n, ctx->d_trace_n, 4, hipMemcpyDeviceToHost));
     if ((int64_t)n > ctx->trace_cap) n = (unsigned)ctx->trace_cap;
     int32_t *ev = (int32_t *)malloc((size_t)std::max(1u, n) * 16 * 4);
     if (!ev) return MTR_ERR_OOM;
-    if (n > 0) HIPCHK(hipMemcpy(ev, ctx->d_trace, (size_t)n * 16 * 4, hipMemcpyDeviceToHost));
+    if (n > 0) HIPCHK(copy_sync(ctx, ev, ctx->d_trace, (size_t)n * 16 * 4, hipMemcpyDeviceToHost));
     *out_events = ev; *out_n = n;
     return MTR_OK;
 }

@@ -10,4 +10,4 @@ eng = mtr_amd.Engine()
 for n in sizes:
     eng.upload(reads[:n]); eng.run(); eng.run()
     c = eng.counters(); kt = eng.kernel_times_ms()
-    print(f"n={n:6d}  K2 {kt['k2_units']:8.1f} ms  K1 {kt['k1_ranges']:7.1f} ms  reads/s {n/(kt['k2_units']+kt['k1_ranges'])*1e3:9.0f}  wave-Mcycles/read {c['cyc_total']/n/1e6:7.1f}", flush=True)
+    print(f"n={n:6d}  K2 {kt['k2_units']:8.1f} ms  K1 {kt['k1_ranges']:7.1f} ms  reads/s {n/(kt['k2_units']+kt['k1_ranges'])*1e3:9.0f}  wave-Mcycles/read {c['cyc_total']/n/1e6:7.1f}  shader clock {c['cyc_total']/max(c['reserved'],1)*100/1e3:5.2f} GHz  wave-ms/read {c['reserved']/n/1e5:6.1f}", flush=True)

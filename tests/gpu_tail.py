@@ -25,3 +25,20 @@ for i in order[len(order)//2: len(order)//2 + 3]:
     print("  read", ev[i, 1], {nm: int(ev[i, 2 + k]) for k, nm in enumerate(names)})
 for k, nm in enumerate(names[:7]):
     print(f"  share {nm:8s} all {ev[:,2+k].sum()/ev[:,2].sum():.3f}   top1% {ev[order[:max(1,len(order)//100)],2+k].sum()/ev[order[:max(1,len(order)//100)],2].sum():.3f}")
+print("correlation of Mcycles/read with:")
+for k, nm in enumerate(names):
+    x = ev[:, 2 + k].astype(np.float64)
+    if x.std() > 0:
+        print(f"  {nm:10s} r = {np.corrcoef(x, tot)[0, 1]:.3f}")
+rng = eng.test_ranges()
+rid = ev[:, 1].astype(int)
+nr = np.array([len(rng[i]) for i in rid], float)
+sl = np.array([sum(e - s + 1 for s, e, w, d in rng[i]) for i in rid], float)
+sw = np.array([sum(w for s, e, w, d in rng[i]) for i in rid], float)
+mx = np.array([max([e - s + 1 for s, e, w, d in rng[i]] or [0]) for i in rid], float)
+for nm, x in (("n_ranges_K1", nr), ("sum_range_len", sl), ("sum_w", sw), ("max_range_len", mx)):
+    print(f"  {nm:14s} r = {np.corrcoef(x, tot)[0, 1]:.3f}")
+A = np.stack([nr, sl, sw, mx, np.ones_like(nr)], 1)
+coef, *_ = np.linalg.lstsq(A, tot, rcond=None)
+pred = A @ coef
+print("  linear fit r =", np.corrcoef(pred, tot)[0, 1], "coef", coef)

@@ -33,7 +33,10 @@ enum { CNT_DP_CALLS = 0, CNT_DP_CELLS, CNT_DP_ROWS, CNT_REV_CALLS, CNT_REV_CELLS
        CNT_GLOBAL_TABLES, CNT_RESERVED15,
        // shader-clock cycles per phase, summed over waves (profiling aid)
        CYC_TOTAL = 16, CYC_DP_FWD, CYC_DP_TB, CYC_TAB_BUILD, CYC_SEEDS, CYC_WALK, CYC_POLISH, CYC_REVISE_VOTE, CYC_SLOT_COPY,
-       CYC_DP_FWD_REV, CYC_DP_TB_REV, CYC_K1_CODES, CYC_K1_PASSES, CYC_K1_EXTRACT, CYC_K1_DEDUP, CYC_K1_TOTAL, CNT_N = 32 };
+       CYC_DP_FWD_REV, CYC_DP_TB_REV, CYC_K1_CODES, CYC_K1_PASSES, CYC_K1_EXTRACT, CYC_K1_DEDUP, CYC_K1_TOTAL,
+       // work the kernel proved it did not have to repeat (results identical by construction)
+       CNT_MEMO_HITS = 32, CNT_MEMO_CELLS, CNT_TABLES_SKIPPED, CNT_SPARE35, CNT_SPARE36, CNT_SPARE37, CNT_SPARE38, CNT_SPARE39,
+       CNT_N = 40 };
 
 // status word values written by the kernels (first error wins)
 enum { DEV_OK = 0, DEV_ERR_RANGE_OVERFLOW = 1, DEV_ERR_RECORD_OVERFLOW = 2, DEV_ERR_DP_TOO_LARGE = 3, DEV_ERR_INTERNAL = 4 };
@@ -96,6 +99,8 @@ static inline __host__ __device__ size_t k1_hist_bytes(int Lmax)
 #define K2_NSLOT 4                 // unit slots: 0 = best of range, 1 = best of k, 2 = candidate, 3 = revision tmp
 #define K2_SLOT_UNIT 1024          // bytes of unit codes per slot (a revised unit can reach 2*499)
 #define K2_SLOT_SCORE 512          // int32 per slot
+#define K2_MEMO_N 32               // wrap_around_DP results remembered per candidate range (<= 11 k x 2 directions are made)
+#define K2_MEMO_UNIT 512           // bytes per remembered unit (MAX_PERIOD - 1 = 499 bases at most)
 struct K2Layout {
     size_t codes;                  // uint8 [cells]  traceback codes
     size_t unit[K2_NSLOT];         // uint8 [1024]
@@ -104,6 +109,7 @@ struct K2Layout {
     size_t pol_u, pol_rev;         // int32 [512] each (polish work arrays)
     size_t gkeys, gvals;           // int32 [gcap]: counts of the k-mer table (always) and keys of windows that do not fit LDS
     size_t ties;                   // int32 [2][1024] tie lists of the look-ahead
+    size_t memo_unit, memo_res;    // DP memo of the current range: uint8 [K2_MEMO_N][512] units, int32 [K2_MEMO_N][16] results
     size_t total;
     size_t cells; unsigned gcap;
 };
@@ -130,6 +136,8 @@ static inline __host__ __device__ K2Layout k2_layout(int Lmax)
     y.pol_u = o; o = mtrc_align(o + 512 * 4, 16);
     y.pol_rev = o; o = mtrc_align(o + 1024 * 4, 16);   // also holds a revised unit (<= 2*499 bases)
     y.ties = o; o = mtrc_align(o + 2 * MTRC_MAX_TIEBREAKS * 4, 16);
+    y.memo_unit = o; o = mtrc_align(o + (size_t)K2_MEMO_N * K2_MEMO_UNIT, 16);
+    y.memo_res = o; o = mtrc_align(o + (size_t)K2_MEMO_N * 16 * 4, 16);
     y.gkeys = o; o = mtrc_align(o + (size_t)g * 4, 16);
     y.gvals = o; o = mtrc_align(o + (size_t)g * 4, 16);
     y.total = mtrc_align(o, 256);

@@ -18,4 +18,5 @@ for label, rs in (("single read", reads[:1]), (f"{n} reads", reads)):
     print(f"   K1 wave-cycles {k1/1e6:.1f} M: codes {100*c['cyc_k1_codes']/max(k1,1):.1f} %  passes {100*c['cyc_k1_passes']/max(k1,1):.1f} %  extract {100*c['cyc_k1_extract']/max(k1,1):.1f} %  dedup+out {100*c['cyc_k1_dedup']/max(k1,1):.1f} %")
     rest = tot - sum(c[k] for k in c if k.startswith("cyc_") and k != "cyc_total" and not k.startswith("cyc_k1"))
     print(f"   {'other':18s} {rest/1e6:10.1f} M  {100.0*rest/max(tot,1):5.1f} %")
+    print(f"   traceback refills: {c['tb_refills']} taking {c['cyc_tb_refill']/1e6:.1f} M cycles = {c['cyc_tb_refill']/max(c['tb_refills'],1):.0f} per refill; memo hits {c['memo_hits']}, tables skipped {c['tables_skipped']}")
     print("   counts:", {k: c[k] for k in ("dp_calls", "dp_rows", "dp_cells", "traceback_steps", "kmer_tables", "kmer_lookups", "ranges_executed")})

@@ -35,7 +35,7 @@ enum { CNT_DP_CALLS = 0, CNT_DP_CELLS, CNT_DP_ROWS, CNT_REV_CALLS, CNT_REV_CELLS
        CYC_TOTAL = 16, CYC_DP_FWD, CYC_DP_TB, CYC_TAB_BUILD, CYC_SEEDS, CYC_WALK, CYC_POLISH, CYC_REVISE_VOTE, CYC_SLOT_COPY,
        CYC_DP_FWD_REV, CYC_DP_TB_REV, CYC_K1_CODES, CYC_K1_PASSES, CYC_K1_EXTRACT, CYC_K1_DEDUP, CYC_K1_TOTAL,
        // work the kernel proved it did not have to repeat (results identical by construction)
-       CNT_MEMO_HITS = 32, CNT_MEMO_CELLS, CNT_TABLES_SKIPPED, CYC_TB_REFILL, CNT_TB_REFILLS, CNT_SPARE37, CNT_SPARE38, CNT_SPARE39,
+       CNT_MEMO_HITS = 32, CNT_MEMO_CELLS, CNT_TABLES_SKIPPED, CYC_TB_REFILL, CNT_TB_REFILLS, CNT_WALK_STEPS, CNT_WALK_SLOW, CYC_WALK_SLOW,
        CNT_N = 40 };
 
 // status word values written by the kernels (first error wins)

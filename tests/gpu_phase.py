@@ -19,4 +19,5 @@ for label, rs in (("single read", reads[:1]), (f"{n} reads", reads)):
     rest = tot - sum(c[k] for k in c if k.startswith("cyc_") and k != "cyc_total" and not k.startswith("cyc_k1"))
     print(f"   {'other':18s} {rest/1e6:10.1f} M  {100.0*rest/max(tot,1):5.1f} %")
     print(f"   traceback refills: {c['tb_refills']} taking {c['cyc_tb_refill']/1e6:.1f} M cycles = {c['cyc_tb_refill']/max(c['tb_refills'],1):.0f} per refill; memo hits {c['memo_hits']}, tables skipped {c['tables_skipped']}")
+    print(f"   walk steps {c['walk_steps']}, of which {c['walk_slow_steps']} through the general look-ahead taking {c['cyc_walk_slow']/1e6:.1f} M cycles")
     print("   counts:", {k: c[k] for k in ("dp_calls", "dp_rows", "dp_cells", "traceback_steps", "kmer_tables", "kmer_lookups", "ranges_executed")})

@@ -24,8 +24,15 @@
 // A read is usable only if L + 2r <= MAX_INPUT_LENGTH (the reference's buffers overflow beyond it).
 #define MTRC_MAX_SUPPORTED_LENGTH 833333
 
-// per-cell traceback codes of the wrap-around DP (one byte per cell in the v1 layout)
-enum { DPC_Z = 0, DPC_M = 1, DPC_X = 2, DPC_DEL = 3, DPC_INS = 4, DPC_PENDING = 5 };
+// Per-cell traceback code of the wrap-around DP = four flags, the same in every cell format:
+//   bit 0: H > 0   bit 1: H != diag - mismatch   bit 2: H != left - indel   bit 3: the bases match.
+// The traceback's priority order (wrap_around_DP.c:304-329) reads: bit 3 -> match; bit 0 clear -> stop; bit 1
+// clear -> mismatch; bit 2 clear -> deletion; else insertion.  The one-parameter kernels store the canonical
+// values below; the packed two-parameter kernel stores the raw flags (a mismatch cell may also have bit 2 set).
+enum { DPC_Z = 0, DPC_X = 1, DPC_DEL = 3, DPC_INS = 7, DPC_M = 8, DPC_PENDING = 15 };
+#define DPC_IS_M(f) (((f) & 8) != 0)
+#define DPC_IS_X(f) (((f) & 11) == 1)
+#define DPC_IS_Z(f) (((f) & 9) == 0)          /* neither a match nor H > 0 */
 
 // device counters (index = MTR counters in include/mtr_hip.h)
 enum { CNT_DP_CALLS = 0, CNT_DP_CELLS, CNT_DP_ROWS, CNT_REV_CALLS, CNT_REV_CELLS, CNT_TABLES, CNT_LOOKUPS,

@@ -43,7 +43,8 @@ enum { CNT_DP_CALLS = 0, CNT_DP_CELLS, CNT_DP_ROWS, CNT_REV_CALLS, CNT_REV_CELLS
        CYC_DP_FWD_REV, CYC_DP_TB_REV, CYC_K1_CODES, CYC_K1_PASSES, CYC_K1_EXTRACT, CYC_K1_DEDUP, CYC_K1_TOTAL,
        // work the kernel proved it did not have to repeat (results identical by construction)
        CNT_MEMO_HITS = 32, CNT_MEMO_CELLS, CNT_TABLES_SKIPPED, CYC_TB_REFILL, CNT_TB_REFILLS, CNT_WALK_STEPS, CNT_WALK_SLOW, CYC_WALK_SLOW,
-       CNT_N = 40 };
+       CNT_WALK_CALLS = 40, CNT_WALK_CLOSED, CYC_WALK_FAST, CNT_SPARE43, CNT_SPARE44, CNT_SPARE45, CNT_SPARE46, CNT_SPARE47,
+       CNT_N = 48 };
 
 // status word values written by the kernels (first error wins)
 enum { DEV_OK = 0, DEV_ERR_RANGE_OVERFLOW = 1, DEV_ERR_RECORD_OVERFLOW = 2, DEV_ERR_DP_TOO_LARGE = 3, DEV_ERR_INTERNAL = 4 };

@@ -458,9 +458,9 @@ extern "C" mtr_status mtr_test_wrap_dp(mtr_ctx *ctx, int32_t n_tasks, const int3
         int rd = read_idx[t];
         int U = unit_off[t + 1] - unit_off[t];
         if (rd < 0 || rd >= ctx->n_reads || query_start[t] < 0 || query_end[t] < query_start[t] || query_end[t] >= ctx->lens[(size_t)rd] || U <= 0 || U >= MTRC_MAX_PERIOD) { ctx->err = "bad DP task " + std::to_string(t); return MTR_ERR_BAD_ARG; }
-        cells = std::max(cells, (size_t)(query_end[t] - query_start[t] + 1) * (size_t)U);
+        cells = std::max(cells, (size_t)(query_end[t] - query_start[t] + 1) * (size_t)(U + 1));   // rows may be padded to an even length
     }
-    size_t per_wave = mtrc_align(cells, 256), total = 0;
+    size_t per_wave = mtrc_align(cells + 256, 256), total = 0;   // + slack: the traceback's dword loads read a few bytes past a row
     int waves = pick_waves(ctx, n_tasks, 8, per_wave, &total);
     DBG("test_wrap_dp: %d tasks, cells %zu, waves %d, scratch %zu", n_tasks, cells, waves, total);
     mtr_status s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;

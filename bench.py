@@ -3,19 +3,20 @@
 
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one pass of the hot path (kernel K1 ranges + kernel K2 units/DP, mtr_run_resident) over one batch of
-synthetic reads that is already resident in HBM (2 bit/base).  Workload = the configuration BASELINE.json's
+A "step" is one pass of the hot path (the per-read kernel mtr_k_reads: candidate ranges, unit search, wrap-around DPs,
+revision; mtr_run_resident) over one batch of synthetic reads that is already resident in HBM (2 bit/base).  Workload = the configuration BASELINE.json's
 metric is quoted on: 10 000 synthetic Nanopore-error reads of ~2 kb (unit 100 x 10 copies, 500-base flanks;
 mtr_amd.synth "headline2k") per GPU.  With N GPUs every rank holds its own 10 000 reads (weak scaling, no
 data-path collective); the step ends with the RCCL gather of the per-read record tables to rank 0 (the one
 exchange step of the path).  Rank 0 prints ONE JSON line.
 
-roofline: the dominant kernel is K2.  `achieved` = algorithmic HBM bytes of one launch (SURVEY.md §8d:
-B_alg = ceil(L/4) + 576 R + sum over DPs of ceil(cells/2), every DP counted as spilled because this build keeps
-all traceback codes in HBM-backed scratch) / K2's average duration measured with HIP events on the launch stream.
-The path is NOT HBM-bound (integer VALU + cross-lane scan latency): the VALU-side figure is reported in
-`roofline.valu` from the counted DP cell updates.  `traffic` = HBM bytes/launch from the rocprofv3 PMC passes
-recorded in profiles/ (null until measured).
+roofline: the only kernel is mtr_k_reads.  `achieved` = algorithmic HBM bytes of one launch (SURVEY.md §8d:
+B_alg = ceil(L/4) + 576 R + sum over the REFERENCE's DPs of ceil(cells/2), every DP counted as spilled because this
+build keeps all traceback cells in HBM-backed scratch; the DPs the kernel answers from its memo are part of the
+reference's work and are counted) / the kernel's average duration measured with HIP events on the launch stream.
+The path is NOT HBM-bound (row-serial integer recurrence: instruction issue + cross-lane scan latency): the
+VALU-side figure is reported in `roofline.valu` from the reference's DP cell updates.  `traffic` = HBM bytes/launch
+from the rocprofv3 PMC passes recorded in profiles/ (null until measured).
 cpu_baseline: rank 0, N=1 only — the reference mTR binary (oracle/_ref/mTR_ref, kind "reference") when it
 travelled with the repo, else the CPU oracle (kind "port"), on the first reads of the same workload, 1 core.
 """
@@ -78,7 +79,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=READS_PER_GPU, help="reads per GPU (default = the headline workload)")
-    ap.add_argument("--cpu-sample", type=int, default=800, help="reads timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2000, help="reads timed on the CPU baseline (0 = skip); 2000 reads ~ 15 s on one core")
     ap.add_argument("--no-latency", action="store_true")
     a = ap.parse_args()
 
@@ -158,12 +159,12 @@ def main():
         n_local = len(reads)
         total_reads = n_local * world * a.steps
         value = total_reads / dt
-        # algorithmic bytes of one K2 launch (this rank's batch)
+        # algorithmic bytes of one launch (this rank's batch): the reference's DP cells = computed + answered from the memo
         sumL4 = sum((len(r) + 3) // 4 for r in reads)
-        b_alg = sumL4 + 576 * cnt["records"] + (cnt["dp_cells"] + cnt["revise_dp_cells"] + 1) // 2
+        cells = cnt["dp_cells"] + cnt["revise_dp_cells"] + cnt["memo_cells"]
+        b_alg = sumL4 + 576 * cnt["records"] + (cells + 1) // 2
         k2_avg_s = float(np.mean(k2_ms)) / 1e3
         achieved_gbs = b_alg / k2_avg_s / 1e9
-        cells = cnt["dp_cells"] + cnt["revise_dp_cells"]
         valu_ops = cells * OPS_PER_CELL / k2_avg_s
         out = {
             "metric": "reads/sec, 2 kb Nanopore synthetic",
@@ -182,17 +183,17 @@ def main():
                                    f"mean L {np.mean([len(r) for r in reads]):.0f}, error profile sub 1.6/ins 9.0/del 3.8 %",
                        "reads_per_gpu": n_local, "parallelism": f"reads sharded over {world} GPU(s), gather to rank 0"},
             "ms_per_read": dt / a.steps * 1e3 / n_local,
-            "kernels_ms": {"k1_ranges": float(np.mean(k1_ms)), "k2_units": float(np.mean(k2_ms)),
+            "kernels_ms": {"mtr_k_reads": float(np.mean(k2_ms)),
                            "note": "HIP-event durations over the timed region; consecutive steps overlap on the GPU, so a launch shares the chip with its neighbour"},
-            "kernels_ms_alone": {"k1_ranges": float(np.mean(sync_k1)) if sync_k1 else None, "k2_units": float(np.mean(sync_k2)) if sync_k2 else None},
-            "work_per_launch": {k: cnt[k] for k in ("dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_dp_cells",
-                                                    "kmer_tables", "kmer_lookups", "ranges_executed", "records", "traceback_steps")},
+            "kernels_ms_alone": {"mtr_k_reads": float(np.mean(sync_k2)) if sync_k2 else None},
+            "work_per_launch": {k: cnt[k] for k in ("dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_dp_cells", "memo_hits", "memo_cells",
+                                                    "kmer_tables", "tables_skipped", "kmer_lookups", "ranges_executed", "records", "traceback_steps")},
             "roofline": {"bound": "hbm", "kernel": "mtr_k_reads", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "algorithmic_bytes_per_launch": b_alg,
                          "valu": {"achieved_lane_ops_per_s": valu_ops, "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
                                   "frac": valu_ops / VALU_PEAK_LANE_OPS, "cells_per_launch": cells, "ops_per_cell": OPS_PER_CELL},
-                         "note": "not HBM-bound: row-serial integer max-plus recurrence (VALU + cross-lane scan latency)"},
+                         "note": "not HBM-bound: row-serial integer max-plus recurrence (instruction issue + cross-lane scan latency); cells = the reference's DP cells, of which memo_cells were answered without a DP"},
         }
         if world == 1 and not a.no_latency:
             lat = []

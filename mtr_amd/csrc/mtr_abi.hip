@@ -70,6 +70,8 @@ struct mtr_ctx {
     bool ran = false, pending = false;
 };
 
+// test knob: MTR_DP16_MAX_ROWS=0 sends every DP through the 32-bit kernels (the fallbacks of reads > 64 kb)
+static int dp16_max_rows() { const char *e = getenv("MTR_DP16_MAX_ROWS"); return e ? atoi(e) : 0x7fffffff; }
 static bool dbg() { static int v = -1; if (v < 0) v = getenv("MTR_DEBUG") ? 1 : 0; return v == 1; }
 #define DBG(...) do { if (dbg()) { fprintf(stderr, "[mtr] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
@@ -277,6 +279,7 @@ static mtr_status launch_reads(mtr_ctx *ctx)
     a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
     a.trace = ctx->d_trace; a.trace_cap = ctx->trace_cap; a.trace_n = ctx->d_trace_n;
     a.trace_mask = getenv("MTR_TRACE_MASK") ? (int32_t)strtol(getenv("MTR_TRACE_MASK"), nullptr, 0) : -1;
+    a.dp16_max_rows = dp16_max_rows();
     HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_trace_n, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
@@ -475,7 +478,7 @@ extern "C" mtr_status mtr_test_wrap_dp(mtr_ctx *ctx, int32_t n_tasks, const int3
     DpTestArgs a;
     a.b = view(ctx); a.n_tasks = n_tasks; a.read_idx = d_rd; a.qs = d_qs; a.qe = d_qe; a.units = d_units; a.unit_off = d_uo;
     a.gain = d_g; a.mism = d_m; a.indel = d_d; a.out8 = d_out; a.scratch = ctx->d_scratch; a.scratch_per_wave = per_wave; a.cells_cap = cells;
-    a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
+    a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters; a.dp16_max_rows = dp16_max_rows();
     HIPCHK(hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));

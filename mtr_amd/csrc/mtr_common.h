@@ -190,6 +190,7 @@ struct K2Args {
     DevRecord *records; int32_t max_rec_per_read; int32_t *rec_count;
     int32_t *status; unsigned int *work_counter; unsigned long long *counters;
     int32_t *trace; int32_t trace_cap; unsigned int *trace_n; int32_t trace_mask;   // bit t = record events of type t
+    int32_t dp16_max_rows;         // DPs of up to this many rows may use the 16-bit kernels (tests set 0 to force the 32-bit ones)
 };
 
 struct DpTestArgs {
@@ -200,4 +201,5 @@ struct DpTestArgs {
     int32_t *out8;
     uint8_t *scratch; size_t scratch_per_wave; size_t cells_cap;
     int32_t *status; unsigned int *work_counter; unsigned long long *counters;
+    int32_t dp16_max_rows;
 };

@@ -193,3 +193,32 @@ def test_bad_arguments(eng):
         eng.process([])
     # the context stays usable after an error
     assert eng.process([np.tile(np.array([3, 3, 0, 2, 2, 2], np.uint8), 80)])[0]     # TTAGGG x 80
+
+
+# ---- the 32-bit DP kernels (what reads longer than 64 kb fall back to), forced through a test knob ------------------
+def test_32bit_dp_fallbacks(monkeypatch, oracle):
+    """MTR_DP16_MAX_ROWS=0 sends every wrap-around DP through dp_forward / dp_forward2 (32-bit values, byte cells)
+    instead of the packed 16-bit kernels: same records, and the golden DP calls of the reference again."""
+    monkeypatch.setenv("MTR_DP16_MAX_ROWS", "0")
+    e = mtr_amd.Engine()
+    reads = [c for _, c in synth.make_reads("headline2k", 48, 77)] + [c for _, c in synth.make_reads("c4", 48, 78)]
+    got = e.process(reads)
+    for i, codes in enumerate(reads):
+        want = oracle.process(codes)
+        assert [tuple(r) for r in got[i]] == want, _diff_msg(i, want, [tuple(r) for r in got[i]])
+    lut = {"A": 0, "C": 1, "G": 2, "T": 3}
+    name = "synth_2k"
+    rd = gu.read_fasta(gu.input_path(name))
+    cap = gu.capture_by_read(name, "default")
+    e.upload([c for _, c in rd])
+    tasks, want = [], []
+    for i, per_read in enumerate(cap):
+        for ev in per_read["G3"]:
+            if len(ev["unit"]) == 0 or ev["qe"] > len(rd[i][1]) - 1:
+                continue
+            tasks.append((i, ev["qs"], ev["qe"], np.array([lut[ch] for ch in ev["unit"]], np.uint8), ev["G"], ev["MM"], ev["D"]))
+            want.append(tuple(ev["out"]))
+    out = e.test_wrap_dp(tasks)
+    bad = [k for k in range(len(tasks)) if tuple(int(x) for x in out[k]) != want[k]]
+    assert not bad, f"{len(bad)} of {len(tasks)} DP calls differ through the 32-bit kernels"
+    e.close()

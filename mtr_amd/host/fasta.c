@@ -39,37 +39,43 @@ mtrh_fasta *mtrh_fasta_open(const char *path)
 void mtrh_fasta_close(mtrh_fasta *f) { if (f) { fclose(f->fp); free(f->pending_id); free(f); } }
 void mtrh_read_free(mtrh_read *r) { free(r->id); free(r->codes); r->id = NULL; r->codes = NULL; r->len = 0; }
 
+/* base code of a character: 0..3 for ACGT/acgt, 0xFE for the characters that end a line (NUL, LF, CR),
+ * 0xFF for everything else (fatal, handle_one_file.c:169-188) */
+static uint8_t code_of[256];
+static void init_codes(void)
+{
+    if (code_of['C'] == 1) return;
+    memset(code_of, 0xFF, sizeof code_of);
+    code_of[0] = code_of['\n'] = code_of['\r'] = 0xFE;
+    code_of['A'] = code_of['a'] = 0; code_of['C'] = code_of['c'] = 1; code_of['G'] = code_of['g'] = 2; code_of['T'] = code_of['t'] = 3;
+}
+
 /* one record; returns 0 at the end of input or at the first empty record (handle_one_file.c:283) */
 static int next_read(mtrh_fasta *f, mtrh_read *out)
 {
     if (f->done) return 0;
+    init_codes();
     uint8_t *codes = NULL; size_t n = 0, cap = 0;
     char *id = f->pending_id; f->pending_id = NULL;
     while (fgets(f->buf, MTRH_BLK, f->fp)) {
-        const char *s = f->buf;
+        const unsigned char *s = (const unsigned char *)f->buf;
         if (s[0] == '>') {
-            if (!f->have_header) { f->have_header = 1; id = header_id(s); continue; }
-            f->pending_id = header_id(s);
+            if (!f->have_header) { f->have_header = 1; id = header_id(f->buf); continue; }
+            f->pending_id = header_id(f->buf);
             if (n == 0) { f->done = 1; free(id); free(codes); return 0; }
             out->id = id; out->codes = codes; out->len = (int32_t)n;
             return 1;
         }
-        for (size_t i = 0; s[i] && s[i] != '\n' && s[i] != '\r'; i++) {
-            uint8_t c;
-            switch (s[i]) {
-            case 'A': case 'a': c = 0; break;
-            case 'C': case 'c': c = 1; break;
-            case 'G': case 'g': c = 2; break;
-            case 'T': case 't': c = 3; break;
-            default: fprintf(stderr, "Invalid character: %c \n", s[i]); exit(EXIT_FAILURE);
-            }
-            if (n == cap) { cap = cap ? cap * 2 : 4096; codes = (uint8_t *)xrealloc(codes, cap); }
-            codes[n++] = c;
-            if (MTR_MAX_INPUT_LENGTH <= (int64_t)n) {
-                fprintf(stderr, "fatal error: The length %d is tentatively at most %i.\nread ID = %s\nSet MAX_INPUT_LENGTH to a larger value", (int)n, MTR_MAX_INPUT_LENGTH, id ? id : "");
-                exit(EXIT_FAILURE);
-            }
+        if (n + MTRH_BLK > cap) { cap = cap ? cap * 2 : 4096; if (cap < n + MTRH_BLK) cap = n + MTRH_BLK; codes = (uint8_t *)xrealloc(codes, cap); }
+        uint8_t *d = codes + n;
+        uint8_t c;
+        while ((c = code_of[*s]) <= 3) { *d++ = c; s++; }
+        n = (size_t)(d - codes);
+        if (MTR_MAX_INPUT_LENGTH <= (int64_t)n) {       /* the reference stops at the base that reaches the limit (before a later bad character) */
+            fprintf(stderr, "fatal error: The length %d is tentatively at most %i.\nread ID = %s\nSet MAX_INPUT_LENGTH to a larger value", MTR_MAX_INPUT_LENGTH, MTR_MAX_INPUT_LENGTH, id ? id : "");
+            exit(EXIT_FAILURE);
         }
+        if (c == 0xFF) { fprintf(stderr, "Invalid character: %c \n", (char)*s); exit(EXIT_FAILURE); }
     }
     f->done = 1;
     if (n == 0) { free(id); free(codes); return 0; }

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <pthread.h>
 #include <sys/time.h>
 
 #define BATCH_READS 65536
@@ -18,6 +19,73 @@ static void usage(void)
     fprintf(stderr, "-c: Print the computation time of each step.\n");
     fprintf(stderr, "-m ratio: Give a minimum match ratio ranging from 0 to 1.\n");
     fprintf(stderr, "-p: Use Pearson's correlation coefficient distance in place of Manhattan distance.\n");
+}
+
+/* ---- double-buffered ingest: a reader thread fills batches, main() consumes them in order ------------------------- */
+typedef struct { mtrh_read *reads; int n; uint8_t *bases; int64_t *offs; int32_t *lens; int state; /* 0 free, 1 full */ } batch_t;
+typedef struct {
+    mtrh_fasta *fa; batch_t slot[2]; int head, tail;      /* producer fills slot[head], consumer takes slot[tail] */
+    pthread_mutex_t mu; pthread_cond_t cv; pthread_t th;
+} ingest_t;
+
+static void *ingest_main(void *arg)
+{
+    ingest_t *g = (ingest_t *)arg;
+    for (;;) {
+        batch_t *b = &g->slot[g->head];
+        pthread_mutex_lock(&g->mu);
+        while (b->state != 0) pthread_cond_wait(&g->cv, &g->mu);
+        pthread_mutex_unlock(&g->mu);
+        const int n = mtrh_fasta_next_batch(g->fa, b->reads, BATCH_READS, BATCH_BASES);
+        b->n = n; b->bases = NULL; b->offs = NULL; b->lens = NULL;
+        if (n > 0) {
+            int64_t total = 0;
+            for (int i = 0; i < n; i++) total += b->reads[i].len;
+            b->bases = (uint8_t *)malloc((size_t)total);
+            b->offs = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+            b->lens = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+            if (!b->bases || !b->offs || !b->lens) { fprintf(stderr, "cannot allocate the batch\n"); exit(EXIT_FAILURE); }
+            int64_t o = 0;
+            for (int i = 0; i < n; i++) { b->offs[i] = o; b->lens[i] = b->reads[i].len; memcpy(b->bases + o, b->reads[i].codes, (size_t)b->reads[i].len); o += b->reads[i].len; }
+        }
+        pthread_mutex_lock(&g->mu);
+        b->state = 1;
+        pthread_cond_broadcast(&g->cv);
+        pthread_mutex_unlock(&g->mu);
+        g->head ^= 1;
+        if (n == 0) return NULL;
+    }
+}
+static void ingest_start(ingest_t *g, mtrh_fasta *fa)
+{
+    memset(g, 0, sizeof(*g));
+    g->fa = fa;
+    for (int k = 0; k < 2; k++) g->slot[k].reads = (mtrh_read *)calloc(BATCH_READS, sizeof(mtrh_read));
+    pthread_mutex_init(&g->mu, NULL); pthread_cond_init(&g->cv, NULL);
+    if (pthread_create(&g->th, NULL, ingest_main, g) != 0) { fprintf(stderr, "cannot start the FASTA thread\n"); exit(EXIT_FAILURE); }
+}
+static batch_t *ingest_take(ingest_t *g)
+{
+    batch_t *b = &g->slot[g->tail];
+    pthread_mutex_lock(&g->mu);
+    while (b->state != 1) pthread_cond_wait(&g->cv, &g->mu);
+    pthread_mutex_unlock(&g->mu);
+    g->tail ^= 1;
+    return b;
+}
+static void ingest_release(ingest_t *g, batch_t *b)
+{
+    free(b->bases); free(b->offs); free(b->lens); b->bases = NULL; b->offs = NULL; b->lens = NULL;
+    pthread_mutex_lock(&g->mu);
+    b->state = 0;
+    pthread_cond_broadcast(&g->cv);
+    pthread_mutex_unlock(&g->mu);
+}
+static void ingest_stop(ingest_t *g)
+{
+    pthread_join(g->th, NULL);
+    for (int k = 0; k < 2; k++) free(g->slot[k].reads);
+    pthread_mutex_destroy(&g->mu); pthread_cond_destroy(&g->cv);
 }
 
 static double now(void) { struct timeval t; gettimeofday(&t, NULL); return t.tv_sec + t.tv_usec * 1.0E-6; }
@@ -47,21 +115,25 @@ int main(int argc, char **argv)
     mtr_status st = mtr_create(device, manhattan, min_match_ratio, &ctx);
     if (st != MTR_OK) { fprintf(stderr, "fatal error: no usable HIP device (mtr_create returned %d); this build has no CPU path\n", (int)st); exit(EXIT_FAILURE); }
 
+    /* FASTA ingest runs ahead of the GPU in its own thread (two batches in flight): while batch b is on the device
+     * and being chained/printed, batch b+1 is parsed and laid out. */
     mtrh_fasta *fa = mtrh_fasta_open(argv[optind]);
-    mtrh_read *reads = (mtrh_read *)calloc(BATCH_READS, sizeof(mtrh_read));
+    ingest_t ing;
+    ingest_start(&ing, fa);
     double t_k1 = 0, t_k2 = 0, t_chain = 0; long long queries = 0;
-    int n;
-    while ((n = mtrh_fasta_next_batch(fa, reads, BATCH_READS, BATCH_BASES)) > 0) {
-        int64_t total = 0;
-        for (int i = 0; i < n; i++) total += reads[i].len;
-        uint8_t *bases = (uint8_t *)malloc((size_t)total);
-        int64_t *offs = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
-        int32_t *lens = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
-        if (!bases || !offs || !lens) { fprintf(stderr, "cannot allocate the batch\n"); exit(EXIT_FAILURE); }
-        int64_t o = 0;
-        for (int i = 0; i < n; i++) { offs[i] = o; lens[i] = reads[i].len; memcpy(bases + o, reads[i].codes, (size_t)reads[i].len); o += reads[i].len; }
+    const int host_timing = getenv("MTR_HOST_TIMING") != NULL;       /* development aid: phase times on stderr */
+    double t_wait = 0, t_proc = 0, t_mark = now();
+    if (host_timing) fprintf(stderr, "[host] create %.3f s\n", now() - t_all);
+    for (;;) {
+        batch_t *b = ingest_take(&ing);
+        t_wait += now() - t_mark;
+        const int n = b->n;
+        if (n == 0) { ingest_release(&ing, b); break; }
+        mtrh_read *reads = b->reads;
         mtr_record *recs = NULL; int32_t *counts = NULL; int64_t nrec = 0;
-        st = mtr_process_batch(ctx, bases, offs, lens, n, &recs, &counts, &nrec);
+        t_mark = now();
+        st = mtr_process_batch(ctx, b->bases, b->offs, b->lens, n, &recs, &counts, &nrec);
+        t_proc += now() - t_mark;
         if (st != MTR_OK) { fprintf(stderr, "%s\n", mtr_last_error(ctx)); exit(EXIT_FAILURE); }
         mtr_kernel_time kt[2]; mtr_get_kernel_times(ctx, kt, 2); t_k1 += kt[0].ms * 1e-3; t_k2 += kt[1].ms * 1e-3;
         int64_t cnt[MTR_N_COUNTERS]; mtr_get_counters(ctx, cnt, MTR_N_COUNTERS); queries += cnt[8];
@@ -79,10 +151,12 @@ int main(int argc, char **argv)
         }
         t_chain += now() - tc;
         mtr_free_results(recs, counts);
-        free(bases); free(offs); free(lens);
+        ingest_release(&ing, b);
+        t_mark = now();
     }
+    ingest_stop(&ing);
+    if (host_timing) fprintf(stderr, "[host] waiting for the FASTA thread %.3f s, mtr_process_batch %.3f s (kernel %.3f s), chain+print %.3f s\n", t_wait, t_proc, t_k1 + t_k2, t_chain);
     mtrh_fasta_close(fa);
-    free(reads);
     mtr_destroy(ctx);
     if (print_time) {                             /* the reference's -c block (main.c:108-121) */
         fprintf(stderr, "Computation time\n");

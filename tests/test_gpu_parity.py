@@ -222,3 +222,21 @@ def test_32bit_dp_fallbacks(monkeypatch, oracle):
     bad = [k for k in range(len(tasks)) if tuple(int(x) for x in out[k]) != want[k]]
     assert not bad, f"{len(bad)} of {len(tasks)} DP calls differ through the 32-bit kernels"
     e.close()
+
+
+def test_very_long_read_with_several_repeats(eng, oracle):
+    """~110 kb read with repeats of 7-, 150- and 300-base units: DP rows beyond the 16-bit kernels' limit for the large
+    windows (32-bit two-parameter pass), units > 256 bases (8 chunks of columns), k-mer tables in global memory."""
+    rng = np.random.RandomState(2024)
+    parts = []
+    for unit_len, copies in ((300, 30), (7, 500), (150, 100), (40, 60)):
+        parts.append(rng.randint(0, 4, size=18000).astype(np.uint8))
+        body, _ = synth.make_read(rng, unit_len, copies, 0, 0)
+        parts.append(body)
+    parts.append(rng.randint(0, 4, size=18000).astype(np.uint8))
+    read = np.concatenate(parts)
+    assert 100000 < len(read) < 140000
+    got = eng.process([read])
+    want = oracle.process(read)
+    assert [tuple(r) for r in got[0]] == want, _diff_msg(0, want, [tuple(r) for r in got[0]])
+    assert len(want) >= 3

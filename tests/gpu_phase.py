@@ -16,7 +16,10 @@ for label, rs in (("single read", reads[:1]), (f"{n} reads", reads)):
         print(f"   {k:18s} {c[k]/1e6:10.1f} M  {100.0*c[k]/max(tot,1):5.1f} %")
     k1 = c["cyc_k1_total"]
     print(f"   K1 wave-cycles {k1/1e6:.1f} M: codes {100*c['cyc_k1_codes']/max(k1,1):.1f} %  passes {100*c['cyc_k1_passes']/max(k1,1):.1f} %  extract {100*c['cyc_k1_extract']/max(k1,1):.1f} %  dedup+out {100*c['cyc_k1_dedup']/max(k1,1):.1f} %")
-    rest = tot - sum(c[k] for k in c if k.startswith("cyc_") and k != "cyc_total" and not k.startswith("cyc_k1"))
+    excl = ("cyc_dp_fwd", "cyc_dp_tb", "cyc_dp_fwd_rev", "cyc_dp_tb_rev", "cyc_tab_build", "cyc_seeds", "cyc_walk", "cyc_polish",
+            "cyc_revise_vote", "cyc_slot_copy", "cyc_k1_total")      # disjoint phases (polish contains one table build: counted twice, small)
+    rest = tot - sum(c[k] for k in excl)
+    print(f"   {'range phase (K1)':18s} {k1/1e6:10.1f} M  {100.0*k1/max(tot,1):5.1f} %")
     print(f"   {'other':18s} {rest/1e6:10.1f} M  {100.0*rest/max(tot,1):5.1f} %")
     print(f"   traceback refills: {c['tb_refills']} taking {c['cyc_tb_refill']/1e6:.1f} M cycles = {c['cyc_tb_refill']/max(c['tb_refills'],1):.0f} per refill; memo hits {c['memo_hits']}, tables skipped {c['tables_skipped']}")
     print(f"   walk steps {c['walk_steps']}, of which {c['walk_slow_steps']} through the general look-ahead taking {c['cyc_walk_slow']/1e6:.1f} M cycles")

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """End-to-end time of the C driver (FASTA in -> report lines out) on a synthetic file (development aid)."""
 import os, subprocess, sys, tempfile, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mtr_amd import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 cfg = sys.argv[2] if len(sys.argv) > 2 else "headline2k"
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 with tempfile.TemporaryDirectory() as td:
     fa = os.path.join(td, "in.fa")
     t0 = time.perf_counter()

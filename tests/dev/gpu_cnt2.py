@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import mtr_amd
 from mtr_amd import synth
 reads = [c for _, c in synth.make_reads("headline2k", 2000, 2)]

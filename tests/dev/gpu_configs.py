@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Other BASELINE configs on the GPU box (development aid): config-3 shape (42 kb reads), a 140 kb read, mixed c4."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import mtr_amd
 from mtr_amd import synth

@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import mtr_amd
 from mtr_amd import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000

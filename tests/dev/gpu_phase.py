@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where K2's cycles go (development aid): phase timers summed over waves, for a single read and a batch."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import mtr_amd
 from mtr_amd import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """K2/K1 time vs batch size (development aid)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import mtr_amd
 from mtr_amd import synth
 sizes = [int(x) for x in sys.argv[1:]] or [64, 256, 1536, 3072, 10000, 20000]

@@ -2,7 +2,7 @@
 """Per-read cost distribution of K2 (development aid): which reads are the stragglers and why."""
 import sys, os
 os.environ["MTR_TRACE_MASK"] = str(1 << 7)
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import mtr_amd
 from mtr_amd import synth

@@ -30,17 +30,26 @@ def is_stale() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
-        return LIB
-    cmd = [hipcc(), *FLAGS, "-o", LIB, os.path.join(CSRC, "mtr_abi.hip")]
-    p = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
-    if p.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + p.stdout + p.stderr)
-    if verbose:
-        print(" ".join(cmd))
+LIB_PROF = os.path.join(HERE, "libmtr_hip_prof.so")      # same code + the per-phase shader-clock timers (-DMTR_PROFILE)
+
+
+def build(force: bool = False, verbose: bool = False, profile: bool = False) -> str:
+    """libmtr_hip.so (product).  profile=True builds libmtr_hip_prof.so as well: the same kernels with the phase timers
+    compiled in (select it with MTR_LIB=.../libmtr_hip_prof.so; tests/dev/gpu_phase.py does)."""
+    targets = [(LIB, [])] + ([(LIB_PROF, ["-DMTR_PROFILE"])] if profile else [])
+    for lib, extra in targets:
+        stale = force or not os.path.exists(lib) or any(os.path.getmtime(os.path.join(CSRC, s)) > os.path.getmtime(lib) for s in SOURCES)
+        if not stale:
+            continue
+        cmd = [hipcc(), *FLAGS, *extra, "-o", lib, os.path.join(CSRC, "mtr_abi.hip")]
+        p = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + p.stdout + p.stderr)
+        if verbose:
+            print(" ".join(cmd))
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force=True, verbose=True, profile="--profile" in sys.argv))

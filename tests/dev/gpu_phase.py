@@ -2,6 +2,7 @@
 """Where K2's cycles go (development aid): phase timers summed over waves, for a single read and a batch."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault("MTR_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "mtr_amd", "libmtr_hip_prof.so"))   # the build with the phase timers
 import mtr_amd
 from mtr_amd import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000

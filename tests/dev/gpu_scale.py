@@ -2,6 +2,7 @@
 """K2/K1 time vs batch size (development aid)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault("MTR_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "mtr_amd", "libmtr_hip_prof.so"))   # the build with the phase timers
 import mtr_amd
 from mtr_amd import synth
 sizes = [int(x) for x in sys.argv[1:]] or [64, 256, 1536, 3072, 10000, 20000]

@@ -4,6 +4,7 @@ import sys, os
 os.environ["MTR_TRACE_MASK"] = str(1 << 7)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
+os.environ.setdefault("MTR_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "mtr_amd", "libmtr_hip_prof.so"))   # the build with the phase timers
 import mtr_amd
 from mtr_amd import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000

@@ -65,6 +65,9 @@ struct mtr_ctx {
     int32_t *d_status = nullptr; unsigned int *d_work = nullptr; unsigned long long *d_counters = nullptr;
     uint8_t *d_scratch = nullptr; size_t scratch_bytes = 0;
     int32_t *d_trace = nullptr; unsigned *d_trace_n = nullptr; int trace_cap = 0;
+    // range-parallel mode (small batches): work items = (read, range), parked candidate records
+    int32_t *d_item_read = nullptr, *d_item_idx = nullptr, *d_cand_flag = nullptr; int64_t *d_item_off = nullptr; DevRecord *d_cand = nullptr;
+    int64_t item_cap = 0; bool last_split = false;
     mtr_kernel_time kt[2] = { { 0, 0 }, { 0, 0 } };
     unsigned long long counters[CNT_N] = { 0 };
     bool ran = false, pending = false;
@@ -94,6 +97,7 @@ static void free_batch(mtr_ctx *ctx)
     dfree(ctx->d_packed); dfree(ctx->d_woff); dfree(ctx->d_lens); dfree(ctx->d_order);
     dfree(ctx->d_roff); dfree(ctx->d_rcount); dfree(ctx->d_rstart); dfree(ctx->d_rend); dfree(ctx->d_rw); dfree(ctx->d_rdi);
     dfree(ctx->d_records); dfree(ctx->d_reccount); dfree(ctx->d_recoff);
+    dfree(ctx->d_item_read); dfree(ctx->d_item_idx); dfree(ctx->d_cand_flag); dfree(ctx->d_item_off); dfree(ctx->d_cand); ctx->item_cap = 0;
     ctx->n_reads = 0; ctx->ran = false;
 }
 
@@ -290,6 +294,77 @@ static mtr_status launch_reads(mtr_ctx *ctx)
     return MTR_OK;
 }
 
+// Range-parallel mode (k2_units.hip.inc): ranges kernel, then every (read, range) as a work item, then the replay of
+// the reference's sequential loop.  Chosen for batches that cannot fill the chip with one wavefront per read;
+// MTR_SPLIT=0/1 forces it off/on, MTR_SPLIT_MAX_READS moves the threshold.
+static bool use_split(const mtr_ctx *ctx)
+{
+    const char *e = getenv("MTR_SPLIT");
+    if (e) return atoi(e) != 0;
+    const char *m = getenv("MTR_SPLIT_MAX_READS");
+    // default: up to as many reads as there are resident wavefront slots (256 CUs x 16).  [measured] 4096 reads of 2 kb:
+    // 50 ms against 63 ms with one wavefront per read; 10 000 reads: 123 ms against 104 ms (the ranges kernel no longer
+    // overlaps the unit searches of other reads, and ~5 % more DP cells are computed for ranges the loop would have skipped)
+    const long max_reads = m ? atol(m) : (long)ctx->n_cu * 16;
+    return ctx->n_reads <= max_reads;
+}
+
+static mtr_status launch_split(mtr_ctx *ctx)
+{
+    const int n = ctx->n_reads;
+    HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    mtr_status s = launch_k1(ctx); if (s != MTR_OK) return s;
+    std::vector<int32_t> rc((size_t)n);
+    HIPCHK(copy_sync(ctx, rc.data(), ctx->d_rcount, (size_t)n * 4, hipMemcpyDeviceToHost));       // waits for the ranges kernel
+    { mtr_status st = check_status(ctx); if (st != MTR_OK) return st; }
+    std::vector<int64_t> ioff((size_t)n + 1, 0);
+    for (int i = 0; i < n; i++) ioff[(size_t)i + 1] = ioff[(size_t)i] + rc[(size_t)i];
+    const int64_t items = ioff[(size_t)n];
+    if (items > 0x7fffffffLL) { ctx->err = "too many candidate ranges for the range-parallel mode"; return MTR_ERR_OVERFLOW; }
+    if (items > ctx->item_cap) {
+        dfree(ctx->d_item_read); dfree(ctx->d_item_idx); dfree(ctx->d_cand_flag); dfree(ctx->d_cand);
+        const int64_t cap = std::max<int64_t>(items, 1);
+        HIPCHK(hipMalloc(&ctx->d_item_read, (size_t)cap * 4)); HIPCHK(hipMalloc(&ctx->d_item_idx, (size_t)cap * 4));
+        HIPCHK(hipMalloc(&ctx->d_cand_flag, (size_t)cap * 4)); HIPCHK(hipMalloc(&ctx->d_cand, (size_t)cap * sizeof(DevRecord)));
+        ctx->item_cap = cap;
+    }
+    if (!ctx->d_item_off) HIPCHK(hipMalloc(&ctx->d_item_off, ((size_t)n + 1) * 8));
+    std::vector<int32_t> iread((size_t)items), iidx((size_t)items);
+    {
+        int64_t p = 0;
+        for (int i = 0; i < n; i++) for (int t = 0; t < rc[(size_t)i]; t++, p++) { iread[(size_t)p] = i; iidx[(size_t)p] = t; }
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_item_read, iread.data(), (size_t)items * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_item_idx, iidx.data(), (size_t)items * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_item_off, ioff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    K2Layout y2 = k2_layout(ctx->Lmax);
+    size_t total = 0;
+    const int waves = pick_waves(ctx, (int)std::max<int64_t>(items, 1), waves_per_cu(), y2.total, &total);
+    s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;
+    K2Args a;
+    a.b = view(ctx); a.min_match_ratio = ctx->min_ratio; a.Lmax = ctx->Lmax;
+    a.scratch = ctx->d_scratch; a.scratch_per_wave = y2.total;
+    a.r_count = ctx->d_rcount; a.r_off = ctx->d_roff; a.r_start = ctx->d_rstart; a.r_end = ctx->d_rend; a.r_w = ctx->d_rw;
+    a.records = ctx->d_records; a.max_rec_per_read = ctx->max_rec; a.rec_count = ctx->d_reccount;
+    a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
+    a.trace = ctx->d_trace; a.trace_cap = ctx->trace_cap; a.trace_n = ctx->d_trace_n;
+    a.trace_mask = getenv("MTR_TRACE_MASK") ? (int32_t)strtol(getenv("MTR_TRACE_MASK"), nullptr, 0) : -1;
+    a.dp16_max_rows = dp16_max_rows();
+    SplitArgs sp;
+    sp.item_read = ctx->d_item_read; sp.item_idx = ctx->d_item_idx; sp.item_off = ctx->d_item_off; sp.n_items = (int32_t)items;
+    sp.cand = ctx->d_cand; sp.cand_flag = ctx->d_cand_flag;
+    HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_trace_n, 0, sizeof(unsigned), ctx->stream));
+    if (items > 0) {
+        hipLaunchKernelGGL(mtr_k_range_units, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a, sp);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(mtr_k_replay, dim3((unsigned)std::min(n, 65535)), dim3(64), 0, ctx->stream, a, sp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+    return MTR_OK;
+}
+
 extern "C" mtr_status mtr_run_resident_async(mtr_ctx *ctx)
 {
     if (!ctx) return MTR_ERR_BAD_ARG;
@@ -298,7 +373,8 @@ extern "C" mtr_status mtr_run_resident_async(mtr_ctx *ctx)
     { mtr_status w = mtr_wait(ctx); if (w != MTR_OK) return w; }
     HIPCHK(hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
-    mtr_status s = launch_reads(ctx); if (s != MTR_OK) return s;
+    ctx->last_split = use_split(ctx);
+    mtr_status s = ctx->last_split ? launch_split(ctx) : launch_reads(ctx); if (s != MTR_OK) return s;
     ctx->pending = true;
     return MTR_OK;
 }

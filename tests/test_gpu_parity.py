@@ -240,3 +240,40 @@ def test_very_long_read_with_several_repeats(eng, oracle):
     want = oracle.process(read)
     assert [tuple(r) for r in got[0]] == want, _diff_msg(0, want, [tuple(r) for r in got[0]])
     assert len(want) >= 3
+
+
+# ---- range-parallel mode (small batches): same records as one wavefront per read -----------------------------------
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_range_parallel_mode_matches(monkeypatch, oracle, split):
+    """MTR_SPLIT=1 searches every candidate range as its own work item and replays the reference's sequential pruning;
+    MTR_SPLIT=0 forces one wavefront per read.  Both must give the oracle's records (and so each other's)."""
+    monkeypatch.setenv("MTR_SPLIT", split)
+    e = mtr_amd.Engine()
+    rng = np.random.RandomState(7)
+    reads = [c for _, c in synth.make_reads("headline2k", 40, 91)] + [c for _, c in synth.make_reads("c4", 40, 92)]
+    reads += [rng.randint(0, 4, size=n).astype(np.uint8) for n in (1, 9, 31, 1000)]
+    reads += [np.tile(np.array([3, 3, 0, 2, 2, 2], np.uint8), 700), c3_read := synth.make_reads("c3", 1, 5)[0][1]]
+    got = e.process(reads)
+    for i, codes in enumerate(reads):
+        want = oracle.process(codes)
+        assert [tuple(r) for r in got[i]] == want, _diff_msg(i, want, [tuple(r) for r in got[i]])
+    e.close()
+
+
+def test_range_parallel_mode_golden(monkeypatch):
+    monkeypatch.setenv("MTR_SPLIT", "1")
+    engines = {"default": mtr_amd.Engine(manhattan=True), "p": mtr_amd.Engine(manhattan=False)}
+    checked = 0
+    for name, mode in gu.cases():
+        if name not in ("2_5_10_20_set", "10_50", "synth_2k", "edge", "3_5"):
+            continue
+        reads = gu.read_fasta(gu.input_path(name))
+        cap = gu.capture_by_read(name, mode)
+        got = engines[mode].process([c for _, c in reads])
+        for i, (per_read, g) in enumerate(zip(cap, got)):
+            want = [gu.g4_tuple(ev) for ev in per_read["G4"]]
+            assert [tuple(r) for r in g] == want, f"{name} [{mode}] " + _diff_msg(i, want, [tuple(r) for r in g])
+        checked += 1
+    assert checked >= 5
+    for e in engines.values():
+        e.close()

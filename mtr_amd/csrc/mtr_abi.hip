@@ -62,12 +62,14 @@ struct mtr_ctx {
     int64_t total_rcap = 0;
     DevRecord *d_records = nullptr; int32_t *d_reccount = nullptr; int max_rec = 0;
     int64_t *d_recoff = nullptr;     // [n_reads+1] exclusive prefix of the record counts (compaction)
+    DevRecord *d_out = nullptr;      // compacted records on their way to the host
     int32_t *d_status = nullptr; unsigned int *d_work = nullptr; unsigned long long *d_counters = nullptr;
     uint8_t *d_scratch = nullptr; size_t scratch_bytes = 0;
     int32_t *d_trace = nullptr; unsigned *d_trace_n = nullptr; int trace_cap = 0;
     // range-parallel mode (small batches): work items = (read, range), parked candidate records
     int32_t *d_item_read = nullptr, *d_item_idx = nullptr, *d_cand_flag = nullptr; int64_t *d_item_off = nullptr; DevRecord *d_cand = nullptr;
     int64_t item_cap = 0; bool last_split = false;
+    std::vector<std::pair<void *, size_t>> caps;       // (address of the pointer member, bytes allocated)
     mtr_kernel_time kt[2] = { { 0, 0 }, { 0, 0 } };
     unsigned long long counters[CNT_N] = { 0 };
     bool ran = false, pending = false;
@@ -91,14 +93,34 @@ static hipError_t copy_sync(mtr_ctx *ctx, void *dst, const void *src, size_t byt
 }
 
 template <typename T> static void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+// Batch buffers are kept between batches and only grow (hipMalloc / hipFree cost ~0.1-0.5 ms each; a dozen of them per
+// batch were a third of a single read's latency).  The capacity of each buffer is remembered by its slot's address.
+template <typename T> static hipError_t ensure_dev(mtr_ctx *ctx, T *&p, size_t bytes);
 
-static void free_batch(mtr_ctx *ctx)
+template <typename T> static hipError_t ensure_dev(mtr_ctx *ctx, T *&p, size_t bytes)
+{
+    void *slot = (void *)&p;
+    size_t *cap = nullptr;
+    for (auto &c : ctx->caps) if (c.first == slot) cap = &c.second;
+    if (!cap) { ctx->caps.emplace_back(slot, (size_t)0); cap = &ctx->caps.back().second; }
+    if (p && bytes <= *cap) return hipSuccess;
+    dfree(p); *cap = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 256);          // head room: batches of similar size reuse the buffer
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) *cap = want;
+    return e;
+}
+
+// forget the resident batch (its buffers stay allocated for the next one)
+static void free_batch(mtr_ctx *ctx) { ctx->n_reads = 0; ctx->ran = false; }
+// release every batch buffer (mtr_destroy)
+static void release_batch_buffers(mtr_ctx *ctx)
 {
     dfree(ctx->d_packed); dfree(ctx->d_woff); dfree(ctx->d_lens); dfree(ctx->d_order);
     dfree(ctx->d_roff); dfree(ctx->d_rcount); dfree(ctx->d_rstart); dfree(ctx->d_rend); dfree(ctx->d_rw); dfree(ctx->d_rdi);
-    dfree(ctx->d_records); dfree(ctx->d_reccount); dfree(ctx->d_recoff);
+    dfree(ctx->d_records); dfree(ctx->d_reccount); dfree(ctx->d_recoff); dfree(ctx->d_out);
     dfree(ctx->d_item_read); dfree(ctx->d_item_idx); dfree(ctx->d_cand_flag); dfree(ctx->d_item_off); dfree(ctx->d_cand); ctx->item_cap = 0;
-    ctx->n_reads = 0; ctx->ran = false;
+    ctx->caps.clear();
 }
 
 extern "C" int mtr_abi_version(void) { return MTR_ABI_VERSION; }
@@ -138,7 +160,7 @@ extern "C" void mtr_destroy(mtr_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    free_batch(ctx);
+    release_batch_buffers(ctx);
     dfree(ctx->d_mt); dfree(ctx->d_status); dfree(ctx->d_work); dfree(ctx->d_counters); dfree(ctx->d_scratch);
     dfree(ctx->d_trace); dfree(ctx->d_trace_n);
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -200,14 +222,15 @@ extern "C" mtr_status mtr_upload_batch(mtr_ctx *ctx, const uint8_t *bases, const
     ctx->lens.assign(lens, lens + n);
     ctx->n_reads = n; ctx->Lmax = Lmax;
     ctx->max_rec = 16 + Lmax / 100;
-    HIPCHK(hipMalloc(&ctx->d_packed, packed.size() * 4));
-    HIPCHK(hipMalloc(&ctx->d_woff, (size_t)n * 8)); HIPCHK(hipMalloc(&ctx->d_lens, (size_t)n * 4)); HIPCHK(hipMalloc(&ctx->d_order, (size_t)n * 4));
-    HIPCHK(hipMalloc(&ctx->d_roff, ((size_t)n + 1) * 8)); HIPCHK(hipMalloc(&ctx->d_rcount, (size_t)n * 4));
-    HIPCHK(hipMalloc(&ctx->d_rstart, (size_t)ctx->total_rcap * 4)); HIPCHK(hipMalloc(&ctx->d_rend, (size_t)ctx->total_rcap * 4));
-    HIPCHK(hipMalloc(&ctx->d_rw, (size_t)ctx->total_rcap * 4)); HIPCHK(hipMalloc(&ctx->d_rdi, (size_t)ctx->total_rcap * 8));
-    HIPCHK(hipMalloc(&ctx->d_records, (size_t)n * (size_t)ctx->max_rec * sizeof(DevRecord)));
-    HIPCHK(hipMalloc(&ctx->d_reccount, (size_t)n * 4));
-    HIPCHK(hipMalloc(&ctx->d_recoff, ((size_t)n + 1) * 8));
+    HIPCHK(ensure_dev(ctx, ctx->d_packed, packed.size() * 4));
+    HIPCHK(ensure_dev(ctx, ctx->d_woff, (size_t)n * 8)); HIPCHK(ensure_dev(ctx, ctx->d_lens, (size_t)n * 4)); HIPCHK(ensure_dev(ctx, ctx->d_order, (size_t)n * 4));
+    HIPCHK(ensure_dev(ctx, ctx->d_roff, ((size_t)n + 1) * 8)); HIPCHK(ensure_dev(ctx, ctx->d_rcount, (size_t)n * 4));
+    HIPCHK(ensure_dev(ctx, ctx->d_rstart, (size_t)ctx->total_rcap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_rend, (size_t)ctx->total_rcap * 4));
+    HIPCHK(ensure_dev(ctx, ctx->d_rw, (size_t)ctx->total_rcap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_rdi, (size_t)ctx->total_rcap * 8));
+    HIPCHK(ensure_dev(ctx, ctx->d_records, (size_t)n * (size_t)ctx->max_rec * sizeof(DevRecord)));
+    HIPCHK(ensure_dev(ctx, ctx->d_reccount, (size_t)n * 4));
+    HIPCHK(ensure_dev(ctx, ctx->d_recoff, ((size_t)n + 1) * 8));
+    HIPCHK(ensure_dev(ctx, ctx->d_item_off, ((size_t)n + 1) * 8));
     HIPCHK(hipMemcpyAsync(ctx->d_packed, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_woff, woff.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_lens, lens, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -321,14 +344,11 @@ static mtr_status launch_split(mtr_ctx *ctx)
     for (int i = 0; i < n; i++) ioff[(size_t)i + 1] = ioff[(size_t)i] + rc[(size_t)i];
     const int64_t items = ioff[(size_t)n];
     if (items > 0x7fffffffLL) { ctx->err = "too many candidate ranges for the range-parallel mode"; return MTR_ERR_OVERFLOW; }
-    if (items > ctx->item_cap) {
-        dfree(ctx->d_item_read); dfree(ctx->d_item_idx); dfree(ctx->d_cand_flag); dfree(ctx->d_cand);
-        const int64_t cap = std::max<int64_t>(items, 1);
-        HIPCHK(hipMalloc(&ctx->d_item_read, (size_t)cap * 4)); HIPCHK(hipMalloc(&ctx->d_item_idx, (size_t)cap * 4));
-        HIPCHK(hipMalloc(&ctx->d_cand_flag, (size_t)cap * 4)); HIPCHK(hipMalloc(&ctx->d_cand, (size_t)cap * sizeof(DevRecord)));
-        ctx->item_cap = cap;
+    {
+        const size_t cap = (size_t)std::max<int64_t>(items, 1);
+        HIPCHK(ensure_dev(ctx, ctx->d_item_read, cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_item_idx, cap * 4));
+        HIPCHK(ensure_dev(ctx, ctx->d_cand_flag, cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_cand, cap * sizeof(DevRecord)));
     }
-    if (!ctx->d_item_off) HIPCHK(hipMalloc(&ctx->d_item_off, ((size_t)n + 1) * 8));
     std::vector<int32_t> iread((size_t)items), iidx((size_t)items);
     {
         int64_t p = 0;
@@ -428,14 +448,14 @@ extern "C" mtr_status mtr_fetch_results(mtr_ctx *ctx, mtr_record **out_records, 
     mtr_record *recs = (mtr_record *)malloc(sizeof(mtr_record) * (size_t)std::max<int64_t>(total, 1));
     if (!recs) { free(counts); return MTR_ERR_OOM; }
     if (total > 0) {
-        DevRecord *d_out = nullptr; int64_t *d_off = ctx->d_recoff;
-        HIPCHK(hipMalloc(&d_out, (size_t)total * sizeof(DevRecord)));
+        int64_t *d_off = ctx->d_recoff;
+        HIPCHK(ensure_dev(ctx, ctx->d_out, (size_t)total * sizeof(DevRecord)));
+        DevRecord *d_out = ctx->d_out;
         HIPCHK(hipMemcpyAsync(d_off, off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(mtr_k_compact, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->d_records, ctx->d_reccount, d_off, ctx->max_rec, n, d_out);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(recs, d_out, (size_t)total * sizeof(DevRecord), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(d_out);
     }
     *out_records = recs; *out_counts = counts; if (out_total) *out_total = total;
     return MTR_OK;

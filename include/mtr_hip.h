@@ -105,6 +105,18 @@ mtr_status mtr_fetch_results(mtr_ctx *ctx, mtr_record **out_records, int32_t **o
  * to RCCL without a host round trip; counts_host receives n_reads per-read counts. */
 mtr_status mtr_export_records_device(mtr_ctx *ctx, void *d_dst, int64_t capacity_records, int32_t *counts_host, int64_t *out_total);
 
+/* The -a alignments (replaces pretty_print_alignment, wrap_around_DP.c:57-213, for the repeats the caller chose to
+ * report, i.e. after chaining): for n records of reads of the RESIDENT batch (mtr_process_batch / mtr_upload_batch
+ * leaves it on the device) the wrap-around alignment of org[rep_start .. rep_end] against the record's unit with the
+ * record's own (match_gain, mismatch_penalty, indel_penalty).  Result: one byte per alignment column in TRACEBACK order
+ * (last column first, as the reference builds its three rows): 1 = match, 2 = mismatch, 3 = gap in the read
+ * (deletion), 4 = gap in the unit (insertion).  (*out_off)[i] .. (*out_off)[i+1] is record i's slice of *out_ops;
+ * (*out_end)[2i] is the 0-origin read position of the last aligned base and (*out_end)[2i+1] the 1-origin unit
+ * column it is aligned to (where the walk back through the columns starts).  The three arrays are malloc'ed;
+ * free() them. */
+mtr_status mtr_alignments(mtr_ctx *ctx, int32_t n, const int32_t *read_idx, const mtr_record *records,
+                          uint8_t **out_ops, int64_t **out_off, int32_t **out_end);
+
 /* Per-kernel device time of the last mtr_run_resident()/mtr_process_batch(), measured with HIP events
  * on the stream the kernels were launched on.  Kernel ids: 0 = ranges (K1), 1 = units+DP (K2). */
 typedef struct mtr_kernel_time { float ms; int32_t launches; } mtr_kernel_time;

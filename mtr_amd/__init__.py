@@ -29,7 +29,7 @@ COUNTER_NAMES = ["dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_d
 EXPORTS = ["mtr_create", "mtr_destroy", "mtr_last_error", "mtr_abi_version", "mtr_process_batch", "mtr_free_results",
            "mtr_upload_batch", "mtr_run_resident", "mtr_fetch_results", "mtr_get_kernel_times", "mtr_get_counters",
            "mtr_test_ranges", "mtr_test_wrap_dp", "mtr_set_trace", "mtr_get_trace", "mtr_export_records_device",
-           "mtr_run_resident_async", "mtr_wait"]
+           "mtr_run_resident_async", "mtr_wait", "mtr_alignments"]
 
 
 class MtrError(RuntimeError):
@@ -102,6 +102,8 @@ def load_library(path: str = LIB_PATH):
     lib.mtr_fetch_results.restype = C.c_int
     lib.mtr_get_kernel_times.argtypes = [C.c_void_p, P(CKernelTime), C.c_int32]
     lib.mtr_get_kernel_times.restype = C.c_int
+    lib.mtr_alignments.argtypes = [C.c_void_p, C.c_int32, P(C.c_int32), C.c_void_p, P(P(C.c_uint8)), P(P(C.c_int64)), P(P(C.c_int32))]
+    lib.mtr_alignments.restype = C.c_int
     lib.mtr_get_counters.argtypes = [C.c_void_p, P(C.c_int64), C.c_int32]
     lib.mtr_get_counters.restype = C.c_int
     lib.mtr_test_ranges.argtypes = [C.c_void_p, P(P(C.c_int32)), P(P(C.c_int32)), P(P(C.c_int32)), P(P(C.c_int32)), P(P(C.c_uint64)), P(C.c_int64)]

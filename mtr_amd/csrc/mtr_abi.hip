@@ -592,6 +592,82 @@ extern "C" mtr_status mtr_test_wrap_dp(mtr_ctx *ctx, int32_t n_tasks, const int3
     return check_status(ctx);
 }
 
+extern "C" mtr_status mtr_alignments(mtr_ctx *ctx, int32_t n, const int32_t *read_idx, const mtr_record *records,
+                                     uint8_t **out_ops, int64_t **out_off, int32_t **out_end)
+{
+    if (!ctx || n < 0 || (n > 0 && (!read_idx || !records)) || !out_ops || !out_off || !out_end) return MTR_ERR_BAD_ARG;
+    if (ctx->n_reads <= 0) { ctx->err = "no batch uploaded"; return MTR_ERR_BAD_ARG; }
+    { mtr_status w = mtr_wait(ctx); if (w != MTR_OK) return w; }
+    HIPCHK(hipSetDevice(ctx->device));
+    int64_t *off = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n + 1));
+    if (!off) return MTR_ERR_OOM;
+    off[0] = 0;
+    if (n == 0) { *out_ops = (uint8_t *)malloc(1); *out_off = off; *out_end = (int32_t *)malloc(8); return MTR_OK; }
+    const size_t nt = (size_t)n;
+    std::vector<int32_t> h((nt * 6) + nt + 1);
+    int32_t *h_rd = h.data(), *h_rs = h_rd + nt, *h_re = h_rs + nt, *h_g = h_re + nt, *h_m = h_g + nt, *h_d = h_m + nt, *h_uo = h_d + nt;
+    std::vector<uint8_t> units; std::vector<int64_t> cap_off(nt + 1, 0);
+    size_t cells = 1;
+    for (int t = 0; t < n; t++) {
+        const mtr_record &r = records[t];
+        const int rd = read_idx[t], U = r.rep_period, rows = r.rep_end - r.rep_start + 1;
+        if (rd < 0 || rd >= ctx->n_reads || U <= 0 || U >= MTRC_MAX_PERIOD || rows <= 0 || r.rep_start < 0 || r.rep_end > ctx->lens[(size_t)rd]) {
+            free(off); ctx->err = "bad alignment task " + std::to_string(t); return MTR_ERR_BAD_ARG;
+        }
+        h_rd[t] = rd; h_rs[t] = r.rep_start; h_re[t] = r.rep_end; h_g[t] = r.match_gain; h_m[t] = r.mismatch_penalty; h_d[t] = r.indel_penalty;
+        h_uo[t] = (int32_t)units.size();
+        for (int j = 0; j < U; j++) { const char ch = r.unit[j]; units.push_back(ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3); }
+        // columns = rows + deletions; every deletion costs indel_penalty out of a score of at most match_gain per row
+        const size_t max_del = (size_t)std::max(r.match_gain, 1) * (size_t)rows / (size_t)std::max(r.indel_penalty, 1);
+        cap_off[(size_t)t + 1] = cap_off[(size_t)t] + (int64_t)(((size_t)rows + max_del + (size_t)U + 64 + 3) & ~(size_t)3);
+        cells = std::max(cells, (size_t)rows * (size_t)(U + 1));
+    }
+    h_uo[n] = (int32_t)units.size();
+    const size_t per_wave = mtrc_align(cells + 256, 256);
+    size_t total = 0;
+    const int waves = pick_waves(ctx, n, 8, per_wave, &total);
+    mtr_status s = ensure_scratch(ctx, total); if (s != MTR_OK) { free(off); return s; }
+    int32_t *d_i32 = nullptr, *d_len = nullptr, *d_ends = nullptr; uint8_t *d_units = nullptr, *d_ops = nullptr; int64_t *d_off = nullptr;
+    int32_t *ends = nullptr;
+    const size_t ops_bytes = (size_t)cap_off[nt];
+    auto fail = [&](mtr_status st) { (void)hipFree(d_i32); (void)hipFree(d_len); (void)hipFree(d_ends); (void)hipFree(d_units); (void)hipFree(d_ops); (void)hipFree(d_off); free(off); free(ends); return st; };
+#define ALN_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return fail(MTR_ERR_HIP); } } while (0)
+    ALN_CHK(hipMalloc(&d_i32, h.size() * 4)); ALN_CHK(hipMalloc(&d_len, nt * 4)); ALN_CHK(hipMalloc(&d_units, units.size() + 16));
+    ALN_CHK(hipMalloc(&d_ops, ops_bytes + 16)); ALN_CHK(hipMalloc(&d_off, (nt + 1) * 8)); ALN_CHK(hipMalloc(&d_ends, nt * 8));
+    ALN_CHK(hipMemcpyAsync(d_i32, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    ALN_CHK(hipMemcpyAsync(d_units, units.data(), units.size(), hipMemcpyHostToDevice, ctx->stream));
+    ALN_CHK(hipMemcpyAsync(d_off, cap_off.data(), (nt + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    AlignArgs a;
+    a.b = view(ctx); a.n_tasks = n;
+    a.read_idx = d_i32; a.rep_start = d_i32 + nt; a.rep_end = d_i32 + 2 * nt; a.gain = d_i32 + 3 * nt; a.mism = d_i32 + 4 * nt; a.indel = d_i32 + 5 * nt;
+    a.unit_off = d_i32 + 6 * nt; a.units = d_units;
+    a.ops = d_ops; a.ops_off = d_off; a.ops_len = d_len; a.ends = d_ends;
+    a.scratch = ctx->d_scratch; a.scratch_per_wave = per_wave; a.cells_cap = cells;
+    a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters; a.dp16_max_rows = dp16_max_rows();
+    ALN_CHK(hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+    ALN_CHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(mtr_k_align, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a);
+    ALN_CHK(hipGetLastError());
+    std::vector<int32_t> len(nt);
+    std::vector<uint8_t> raw(ops_bytes);
+    ends = (int32_t *)malloc(nt * 8);
+    if (!ends) return fail(MTR_ERR_OOM);
+    ALN_CHK(hipMemcpyAsync(ends, d_ends, nt * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ALN_CHK(hipMemcpyAsync(len.data(), d_len, nt * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ALN_CHK(hipMemcpyAsync(raw.data(), d_ops, ops_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ALN_CHK(hipStreamSynchronize(ctx->stream));
+#undef ALN_CHK
+    { mtr_status st = check_status(ctx); if (st != MTR_OK) return fail(st); }
+    for (int t = 0; t < n; t++) off[(size_t)t + 1] = off[(size_t)t] + len[(size_t)t];
+    uint8_t *ops = (uint8_t *)malloc((size_t)std::max<int64_t>(off[nt], 1));
+    if (!ops) return fail(MTR_ERR_OOM);
+    for (int t = 0; t < n; t++) memcpy(ops + off[(size_t)t], raw.data() + cap_off[(size_t)t], (size_t)len[(size_t)t]);
+    (void)hipFree(d_i32); (void)hipFree(d_len); (void)hipFree(d_ends); (void)hipFree(d_units); (void)hipFree(d_ops); (void)hipFree(d_off);
+    for (int t = 0; t < n; t++) ends[2 * t] = records[t].rep_start - 1 + ends[2 * t];       // window row -> read position
+    *out_ops = ops; *out_off = off; *out_end = ends;
+    return MTR_OK;
+}
+
 extern "C" mtr_status mtr_set_trace(mtr_ctx *ctx, int32_t max_events)
 {
     if (!ctx || max_events < 0) return MTR_ERR_BAD_ARG;

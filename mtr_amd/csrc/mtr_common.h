@@ -193,6 +193,19 @@ struct K2Args {
     int32_t dp16_max_rows;         // DPs of up to this many rows may use the 16-bit kernels (tests set 0 to force the 32-bit ones)
 };
 
+// -a alignments (pretty_print_alignment, wrap_around_DP.c:57-213) of a list of reported repeats of the resident batch
+struct AlignArgs {
+    BatchView b;
+    int32_t n_tasks;
+    const int32_t *read_idx, *rep_start, *rep_end, *gain, *mism, *indel;
+    const uint8_t *units; const int32_t *unit_off;     // unit codes 0..3, concatenated
+    uint8_t *ops; const int64_t *ops_off; int32_t *ops_len;   // task t writes ops[ops_off[t] .. ops_off[t+1]) and its length
+    int32_t *ends;                 // [2t] = row (1-origin in the window), [2t+1] = unit column (1-origin) of the path's last cell
+    uint8_t *scratch; size_t scratch_per_wave; size_t cells_cap;
+    int32_t *status; unsigned int *work_counter; unsigned long long *counters;
+    int32_t dp16_max_rows;
+};
+
 struct DpTestArgs {
     BatchView b;
     int32_t n_tasks;

@@ -138,16 +138,48 @@ int main(int argc, char **argv)
         mtr_kernel_time kt[2]; mtr_get_kernel_times(ctx, kt, 2); t_k1 += kt[0].ms * 1e-3; t_k2 += kt[1].ms * 1e-3;
         int64_t cnt[MTR_N_COUNTERS]; mtr_get_counters(ctx, cnt, MTR_N_COUNTERS); queries += cnt[8];
         const double tc = now();
-        int64_t p = 0;
-        for (int i = 0; i < n; i++) {
-            if (counts[i] > 0) {
-                int *chain = (int *)malloc(sizeof(int) * (size_t)counts[i]);
-                int nc = mtrh_chain(recs + p, counts[i], chain);
-                mtrh_print_chain(stdout, &reads[i], recs + p, chain, nc, print_alignment);
-                free(chain);
+        if (!print_alignment) {
+            int64_t p = 0;
+            for (int i = 0; i < n; i++) {
+                if (counts[i] > 0) {
+                    int *chain = (int *)malloc(sizeof(int) * (size_t)counts[i]);
+                    int nc = mtrh_chain(recs + p, counts[i], chain);
+                    mtrh_print_chain(stdout, &reads[i], recs + p, chain, nc, 0);
+                    free(chain);
+                }
+                p += counts[i];
+                mtrh_read_free(&reads[i]);
             }
-            p += counts[i];
-            mtrh_read_free(&reads[i]);
+        } else {
+            /* -a: chain every read first, then ONE device call aligns all reported repeats of the batch (the batch is
+             * still resident), then print in input order */
+            int *chains = (int *)malloc(sizeof(int) * (size_t)(nrec > 0 ? nrec : 1));
+            int *nchain = (int *)calloc((size_t)n, sizeof(int));
+            int64_t *cfirst = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+            int64_t p = 0, ntask = 0;
+            for (int i = 0; i < n; i++) {
+                cfirst[i] = ntask;
+                if (counts[i] > 0) { nchain[i] = mtrh_chain(recs + p, counts[i], chains + p); ntask += nchain[i]; }
+                p += counts[i];
+            }
+            int32_t *t_read = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ntask > 0 ? ntask : 1));
+            mtr_record *t_rec = (mtr_record *)malloc(sizeof(mtr_record) * (size_t)(ntask > 0 ? ntask : 1));
+            if (!chains || !nchain || !cfirst || !t_read || !t_rec) { fprintf(stderr, "cannot allocate the alignment tasks\n"); exit(EXIT_FAILURE); }
+            p = 0;
+            for (int i = 0; i < n; i++) {
+                for (int t = 0; t < nchain[i]; t++) { t_read[cfirst[i] + t] = i; t_rec[cfirst[i] + t] = recs[p + chains[p + t]]; }
+                p += counts[i];
+            }
+            uint8_t *ops = NULL; int64_t *ooff = NULL; int32_t *ends = NULL;
+            st = mtr_alignments(ctx, (int32_t)ntask, t_read, t_rec, &ops, &ooff, &ends);
+            if (st != MTR_OK) { fprintf(stderr, "%s\n", mtr_last_error(ctx)); exit(EXIT_FAILURE); }
+            p = 0;
+            for (int i = 0; i < n; i++) {
+                if (nchain[i] > 0) mtrh_print_chain_ops(stdout, &reads[i], recs + p, chains + p, nchain[i], ops, ooff, ends, cfirst[i]);
+                p += counts[i];
+                mtrh_read_free(&reads[i]);
+            }
+            free(ops); free(ooff); free(ends); free(chains); free(nchain); free(cfirst); free(t_read); free(t_rec);
         }
         t_chain += now() - tc;
         mtr_free_results(recs, counts);

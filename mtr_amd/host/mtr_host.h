@@ -33,4 +33,7 @@ int  mtrh_chain(const mtr_record *recs, int n, int *chain);
 
 /* chaining.cpp:125-171: one report line per chained repeat (+ the alignment block with -a) */
 void mtrh_print_chain(FILE *fp, const mtrh_read *rd, const mtr_record *recs, const int *chain, int n_chain, int print_alignment);
+/* the same with the alignment blocks taken from mtr_alignments() (device) instead of a DP on the host */
+void mtrh_print_chain_ops(FILE *fp, const mtrh_read *rd, const mtr_record *recs, const int *chain, int n_chain,
+                          const uint8_t *ops, const int64_t *off, const int32_t *ends, int64_t first_task);
 #endif

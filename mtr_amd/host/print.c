@@ -79,6 +79,56 @@ static void print_alignment(FILE *fp, const mtrh_read *rd, const mtr_record *r)
     free(unit); free(prev); free(cur); free(tb); free(a_in); free(a_sym); free(a_rep);
 }
 
+/* The same block from the path the device returned (mtr_alignments): ops[] = one byte per column, last column first
+ * (1 match, 2 mismatch, 3 gap in the read, 4 gap in the unit); end_pos = read position of the last aligned base,
+ * end_col = 1-origin unit column it is aligned to. */
+static void print_alignment_ops(FILE *fp, const mtrh_read *rd, const mtr_record *r, const uint8_t *ops, int64_t n_ops, int end_pos, int end_col)
+{
+    const int U = r->rep_period;
+    fprintf(fp, "match gain = %i, mismatch penalty = %i, indel penalty = %i\n\n", r->match_gain, r->mismatch_penalty, r->indel_penalty);
+    if (U <= 0 || n_ops <= 0) return;
+    char *a_in = (char *)malloc((size_t)n_ops), *a_sym = (char *)malloc((size_t)n_ops), *a_rep = (char *)malloc((size_t)n_ops);
+    if (!a_in || !a_sym || !a_rep) { fprintf(stderr, "cannot allocate the alignment rows\n"); exit(EXIT_FAILURE); }
+    int p = end_pos, j = end_col;
+    for (int64_t q = 0; q < n_ops; q++) {
+        const int c = ops[q];
+        const char xb = BASE[(p >= 0 && p < rd->len) ? rd->codes[p] : 0];
+        const char ub = r->unit[j - 1];
+        if (c == T_MATCH) { a_in[q] = xb; a_sym[q] = '|'; a_rep[q] = ub; p--; j--; }
+        else if (c == T_MISMATCH) { a_in[q] = xb; a_sym[q] = ' '; a_rep[q] = ub; p--; j--; }
+        else if (c == T_DEL) { a_in[q] = '-'; a_sym[q] = ' '; a_rep[q] = ub; j--; }
+        else { a_in[q] = xb; a_sym[q] = ' '; a_rep[q] = '-'; p--; }
+        if (j == 0) j = U;
+    }
+    for (long s = (long)n_ops - 1; 0 <= s; s -= MTRH_ALIGN_WIDTH) {
+        const long e = (-1 <= s - MTRH_ALIGN_WIDTH) ? s - MTRH_ALIGN_WIDTH : -1;
+        for (long q = s; e < q; q--) fputc(a_in[q], fp);
+        fputc('\n', fp);
+        for (long q = s; e < q; q--) fputc(a_sym[q], fp);
+        fputc('\n', fp);
+        for (long q = s; e < q; q--) fputc(a_rep[q], fp);
+        fputs("\n\n", fp);
+    }
+    free(a_in); free(a_sym); free(a_rep);
+}
+
+/* report lines of one chain with the alignment blocks computed on the device: ops/off/ends as returned by
+ * mtr_alignments for this chain's records, first_task = index of the chain's first record among the tasks */
+void mtrh_print_chain_ops(FILE *fp, const mtrh_read *rd, const mtr_record *recs, const int *chain, int n_chain,
+                          const uint8_t *ops, const int64_t *off, const int32_t *ends, int64_t first_task)
+{
+    for (int t = 0; t < n_chain; t++) {
+        const mtr_record *r = &recs[chain[t]];
+        fprintf(fp, "%s\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%f\t%d\t%d\t%d\t%s\n", rd->id, rd->len, r->rep_start + 1, r->rep_end + 1,
+                r->repeat_len, r->rep_period, r->num_freq_unit, r->num_matches, (float)r->num_matches / r->repeat_len,
+                r->num_mismatches, r->num_insertions, r->num_deletions, r->unit);
+        const int64_t k = first_task + t;
+        fputc('\n', fp);
+        print_alignment_ops(fp, rd, r, ops + off[k], off[k + 1] - off[k], ends[2 * k], ends[2 * k + 1]);
+        fflush(fp);
+    }
+}
+
 void mtrh_print_chain(FILE *fp, const mtrh_read *rd, const mtr_record *recs, const int *chain, int n_chain, int print_align)
 {
     for (int t = 0; t < n_chain; t++) {

@@ -289,6 +289,49 @@ static mtr_status launch_k1(mtr_ctx *ctx)
     return MTR_OK;
 }
 
+// number of (k,w) passes of a read of length L (fill_directional_index.c:559-582; same enumeration as k1_read)
+static int k1_num_passes(int L)
+{
+    int np = 0;
+    for (int k = 1; k <= 5; k += 2) {
+        const int max_w = (k == 1) ? 20 : (k == 3 ? 80 : MTRC_MAX_WINDOW);
+        for (int w = MTRC_MIN_WINDOW; w <= max_w && w < L / 2; w *= 2) np++;
+    }
+    return np;
+}
+
+// The range finder as three kernels over per-READ scratch: code arrays, one wavefront per (read, pass), extraction +
+// de-duplication.  For batches of few reads (the passes of a read otherwise take turns inside one wavefront).
+static mtr_status launch_k1_parts(mtr_ctx *ctx)
+{
+    const int n = ctx->n_reads;
+    K1Layout y = k1_layout(ctx->Lmax);
+    mtr_status s = ensure_scratch(ctx, (size_t)n * y.total); if (s != MTR_OK) return s;
+    std::vector<int32_t> iread, ipass;
+    for (int i = 0; i < n; i++) { const int np = k1_num_passes(ctx->lens[(size_t)i]); for (int p = 0; p < np; p++) { iread.push_back(i); ipass.push_back(p); } }
+    const size_t items = iread.size();
+    HIPCHK(ensure_dev(ctx, ctx->d_item_read, std::max<size_t>(items, 1) * 4)); HIPCHK(ensure_dev(ctx, ctx->d_item_idx, std::max<size_t>(items, 1) * 4));
+    if (items > 0) {
+        HIPCHK(hipMemcpyAsync(ctx->d_item_read, iread.data(), items * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->d_item_idx, ipass.data(), items * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    K1Args a; k1_args(ctx, a, y.total);
+    const int slots = ctx->n_cu * waves_per_cu();
+    HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(mtr_k1_part, dim3((unsigned)std::min(n, slots)), dim3(64), 0, ctx->stream, a, (int)K1_CODES, (const int32_t *)nullptr, (const int32_t *)nullptr, n);
+    HIPCHK(hipGetLastError());
+    if (items > 0) {
+        HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
+        hipLaunchKernelGGL(mtr_k1_part, dim3((unsigned)std::min<size_t>(items, (size_t)slots)), dim3(64), 0, ctx->stream, a, (int)K1_PASSES,
+                           (const int32_t *)ctx->d_item_read, (const int32_t *)ctx->d_item_idx, (int)items);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(mtr_k1_part, dim3((unsigned)std::min(n, slots)), dim3(64), 0, ctx->stream, a, (int)K1_FINISH, (const int32_t *)nullptr, (const int32_t *)nullptr, n);
+    HIPCHK(hipGetLastError());
+    return MTR_OK;
+}
+
 // the per-read kernel: ranges (K1 code) and unit search / DP (K2 code) of a read by the same wavefront
 static mtr_status launch_reads(mtr_ctx *ctx)
 {
@@ -336,7 +379,10 @@ static mtr_status launch_split(mtr_ctx *ctx)
 {
     const int n = ctx->n_reads;
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
-    mtr_status s = launch_k1(ctx); if (s != MTR_OK) return s;
+    // few reads: one wavefront per (read, pass) in the range finder too (MTR_K1_PARTS_MAX_READS, default 256 reads:
+    // [measured] 1 read 7.6 -> 6.5 ms, 100 reads of 42 kb 403 -> 348 ms, but 1024 reads of 2 kb 40 -> 45 ms)
+    const long parts_max = getenv("MTR_K1_PARTS_MAX_READS") ? atol(getenv("MTR_K1_PARTS_MAX_READS")) : 256;
+    mtr_status s = (n <= parts_max) ? launch_k1_parts(ctx) : launch_k1(ctx); if (s != MTR_OK) return s;
     std::vector<int32_t> rc((size_t)n);
     HIPCHK(copy_sync(ctx, rc.data(), ctx->d_rcount, (size_t)n * 4, hipMemcpyDeviceToHost));       // waits for the ranges kernel
     { mtr_status st = check_status(ctx); if (st != MTR_OK) return st; }

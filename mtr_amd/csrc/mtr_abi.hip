@@ -183,6 +183,15 @@ static int pick_waves(mtr_ctx *ctx, int n_items, int per_cu, size_t per_wave, si
     size_t free_b = 0, tot_b = 0;
     if (hipMemGetInfo(&free_b, &tot_b) != hipSuccess) free_b = (size_t)8 << 30;
     size_t budget = (size_t)((double)(free_b + ctx->scratch_bytes) * 0.7);
+    // Scratch is sized for the worst DP of the longest read (L x 499 cells per wavefront): 4096 wavefronts of 42 kb reads
+    // would take 86 GB, and an allocation of that size right after another process freed the memory takes seconds
+    // ([measured] 2-6 s for 86 GB, 0.5-1.3 s for 32 GB, none for 8 GB).  Past MTR_SCRATCH_MAX_GB (default 16) fewer
+    // wavefronts run; 10 000 reads of 2 kb need 6 GB.
+    {
+        const char *e = getenv("MTR_SCRATCH_MAX_GB");
+        const size_t cap = (size_t)(e ? atof(e) : 16.0) << 30;
+        if (budget > cap) budget = cap;
+    }
     long waves = (long)ctx->n_cu * per_cu;
     if (waves > n_items) waves = n_items;
     if (waves < 1) waves = 1;

@@ -9,7 +9,8 @@
 #include <pthread.h>
 #include <sys/time.h>
 
-#define BATCH_READS 65536
+#define BATCH_READS 16384            /* reads per device batch: two batches overlap on the GPU (two contexts) */
+#define N_SLOTS 3                    /* ingest ring: one batch being parsed, one on the device, one being printed */
 #define BATCH_BASES (512LL << 20)
 
 static void usage(void)
@@ -24,7 +25,7 @@ static void usage(void)
 /* ---- double-buffered ingest: a reader thread fills batches, main() consumes them in order ------------------------- */
 typedef struct { mtrh_read *reads; int n; uint8_t *bases; int64_t *offs; int32_t *lens; int state; /* 0 free, 1 full */ } batch_t;
 typedef struct {
-    mtrh_fasta *fa; batch_t slot[2]; int head, tail;      /* producer fills slot[head], consumer takes slot[tail] */
+    mtrh_fasta *fa; batch_t slot[N_SLOTS]; int head, tail;      /* producer fills slot[head], consumer takes slot[tail] */
     pthread_mutex_t mu; pthread_cond_t cv; pthread_t th;
 } ingest_t;
 
@@ -52,7 +53,7 @@ static void *ingest_main(void *arg)
         b->state = 1;
         pthread_cond_broadcast(&g->cv);
         pthread_mutex_unlock(&g->mu);
-        g->head ^= 1;
+        g->head = (g->head + 1) % N_SLOTS;
         if (n == 0) return NULL;
     }
 }
@@ -60,7 +61,7 @@ static void ingest_start(ingest_t *g, mtrh_fasta *fa)
 {
     memset(g, 0, sizeof(*g));
     g->fa = fa;
-    for (int k = 0; k < 2; k++) g->slot[k].reads = (mtrh_read *)calloc(BATCH_READS, sizeof(mtrh_read));
+    for (int k = 0; k < N_SLOTS; k++) g->slot[k].reads = (mtrh_read *)calloc(BATCH_READS, sizeof(mtrh_read));
     pthread_mutex_init(&g->mu, NULL); pthread_cond_init(&g->cv, NULL);
     if (pthread_create(&g->th, NULL, ingest_main, g) != 0) { fprintf(stderr, "cannot start the FASTA thread\n"); exit(EXIT_FAILURE); }
 }
@@ -70,7 +71,7 @@ static batch_t *ingest_take(ingest_t *g)
     pthread_mutex_lock(&g->mu);
     while (b->state != 1) pthread_cond_wait(&g->cv, &g->mu);
     pthread_mutex_unlock(&g->mu);
-    g->tail ^= 1;
+    g->tail = (g->tail + 1) % N_SLOTS;
     return b;
 }
 static void ingest_release(ingest_t *g, batch_t *b)
@@ -84,8 +85,71 @@ static void ingest_release(ingest_t *g, batch_t *b)
 static void ingest_stop(ingest_t *g)
 {
     pthread_join(g->th, NULL);
-    for (int k = 0; k < 2; k++) free(g->slot[k].reads);
+    for (int k = 0; k < N_SLOTS; k++) free(g->slot[k].reads);
     pthread_mutex_destroy(&g->mu); pthread_cond_destroy(&g->cv);
+}
+
+typedef struct { int print_alignment; double t_wait, t_submit, t_fetch, t_kernel, t_chain; long long queries; } run_t;
+static double now(void);
+
+/* a batch whose kernels were started: wait, fetch the records, chain and print every read in input order */
+static void finish_batch(run_t *run, mtr_ctx *ctx, batch_t *b)
+{
+    const int n = b->n;
+    mtrh_read *reads = b->reads;
+    mtr_record *recs = NULL; int32_t *counts = NULL; int64_t nrec = 0;
+    double t_mark = now();
+    mtr_status st = mtr_fetch_results(ctx, &recs, &counts, &nrec);
+    if (st != MTR_OK) { fprintf(stderr, "%s\n", mtr_last_error(ctx)); exit(EXIT_FAILURE); }
+    run->t_fetch += now() - t_mark;
+    mtr_kernel_time kt[2]; mtr_get_kernel_times(ctx, kt, 2); run->t_kernel += (kt[0].ms + kt[1].ms) * 1e-3;
+    int64_t cnt[MTR_N_COUNTERS]; mtr_get_counters(ctx, cnt, MTR_N_COUNTERS); run->queries += cnt[8];
+    const double tc = now();
+    if (!run->print_alignment) {
+        int64_t p = 0;
+        for (int i = 0; i < n; i++) {
+            if (counts[i] > 0) {
+                int *chain = (int *)malloc(sizeof(int) * (size_t)counts[i]);
+                int nc = mtrh_chain(recs + p, counts[i], chain);
+                mtrh_print_chain(stdout, &reads[i], recs + p, chain, nc, 0);
+                free(chain);
+            }
+            p += counts[i];
+            mtrh_read_free(&reads[i]);
+        }
+    } else {
+        /* -a: chain every read first, then ONE device call aligns all reported repeats of the batch (the batch is
+         * still resident in this context), then print in input order */
+        int *chains = (int *)malloc(sizeof(int) * (size_t)(nrec > 0 ? nrec : 1));
+        int *nchain = (int *)calloc((size_t)n, sizeof(int));
+        int64_t *cfirst = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+        int64_t p = 0, ntask = 0;
+        for (int i = 0; i < n; i++) {
+            cfirst[i] = ntask;
+            if (counts[i] > 0) { nchain[i] = mtrh_chain(recs + p, counts[i], chains + p); ntask += nchain[i]; }
+            p += counts[i];
+        }
+        int32_t *t_read = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ntask > 0 ? ntask : 1));
+        mtr_record *t_rec = (mtr_record *)malloc(sizeof(mtr_record) * (size_t)(ntask > 0 ? ntask : 1));
+        if (!chains || !nchain || !cfirst || !t_read || !t_rec) { fprintf(stderr, "cannot allocate the alignment tasks\n"); exit(EXIT_FAILURE); }
+        p = 0;
+        for (int i = 0; i < n; i++) {
+            for (int t = 0; t < nchain[i]; t++) { t_read[cfirst[i] + t] = i; t_rec[cfirst[i] + t] = recs[p + chains[p + t]]; }
+            p += counts[i];
+        }
+        uint8_t *ops = NULL; int64_t *ooff = NULL; int32_t *ends = NULL;
+        st = mtr_alignments(ctx, (int32_t)ntask, t_read, t_rec, &ops, &ooff, &ends);
+        if (st != MTR_OK) { fprintf(stderr, "%s\n", mtr_last_error(ctx)); exit(EXIT_FAILURE); }
+        p = 0;
+        for (int i = 0; i < n; i++) {
+            if (nchain[i] > 0) mtrh_print_chain_ops(stdout, &reads[i], recs + p, chains + p, nchain[i], ops, ooff, ends, cfirst[i]);
+            p += counts[i];
+            mtrh_read_free(&reads[i]);
+        }
+        free(ops); free(ooff); free(ends); free(chains); free(nchain); free(cfirst); free(t_read); free(t_rec);
+    }
+    run->t_chain += now() - tc;
+    mtr_free_results(recs, counts);
 }
 
 static double now(void) { struct timeval t; gettimeofday(&t, NULL); return t.tv_sec + t.tv_usec * 1.0E-6; }
@@ -111,85 +175,45 @@ int main(int argc, char **argv)
     if (optind >= argc) { fprintf(stderr, "The input file name is expected argument after options\n"); exit(EXIT_FAILURE); }
 
     const double t_all = now();
-    mtr_ctx *ctx = NULL;
-    mtr_status st = mtr_create(device, manhattan, min_match_ratio, &ctx);
+    /* Two contexts = two device batches in flight: batch b+1 is packed, uploaded and started while batch b is still
+     * running; batch b is then fetched, chained and printed while b+1 runs.  Output order = input order. */
+    mtr_ctx *ctxs[2] = { NULL, NULL };
+    mtr_status st = MTR_OK;
+    for (int k = 0; k < 2 && st == MTR_OK; k++) st = mtr_create(device, manhattan, min_match_ratio, &ctxs[k]);
     if (st != MTR_OK) { fprintf(stderr, "fatal error: no usable HIP device (mtr_create returned %d); this build has no CPU path\n", (int)st); exit(EXIT_FAILURE); }
 
-    /* FASTA ingest runs ahead of the GPU in its own thread (two batches in flight): while batch b is on the device
-     * and being chained/printed, batch b+1 is parsed and laid out. */
     mtrh_fasta *fa = mtrh_fasta_open(argv[optind]);
     ingest_t ing;
     ingest_start(&ing, fa);
-    double t_k1 = 0, t_k2 = 0, t_chain = 0; long long queries = 0;
     const int host_timing = getenv("MTR_HOST_TIMING") != NULL;       /* development aid: phase times on stderr */
-    double t_wait = 0, t_proc = 0, t_mark = now();
     if (host_timing) fprintf(stderr, "[host] create %.3f s\n", now() - t_all);
-    for (;;) {
+    run_t run; memset(&run, 0, sizeof run);
+    run.print_alignment = print_alignment;
+    batch_t *prev = NULL; mtr_ctx *prev_ctx = NULL;
+    for (int k = 0;; k++) {
+        double t_mark = now();
         batch_t *b = ingest_take(&ing);
-        t_wait += now() - t_mark;
-        const int n = b->n;
-        if (n == 0) { ingest_release(&ing, b); break; }
-        mtrh_read *reads = b->reads;
-        mtr_record *recs = NULL; int32_t *counts = NULL; int64_t nrec = 0;
+        run.t_wait += now() - t_mark;
+        if (b->n == 0) { ingest_release(&ing, b); break; }
+        mtr_ctx *ctx = ctxs[k & 1];
         t_mark = now();
-        st = mtr_process_batch(ctx, b->bases, b->offs, b->lens, n, &recs, &counts, &nrec);
-        t_proc += now() - t_mark;
-        if (st != MTR_OK) { fprintf(stderr, "%s\n", mtr_last_error(ctx)); exit(EXIT_FAILURE); }
-        mtr_kernel_time kt[2]; mtr_get_kernel_times(ctx, kt, 2); t_k1 += kt[0].ms * 1e-3; t_k2 += kt[1].ms * 1e-3;
-        int64_t cnt[MTR_N_COUNTERS]; mtr_get_counters(ctx, cnt, MTR_N_COUNTERS); queries += cnt[8];
-        const double tc = now();
-        if (!print_alignment) {
-            int64_t p = 0;
-            for (int i = 0; i < n; i++) {
-                if (counts[i] > 0) {
-                    int *chain = (int *)malloc(sizeof(int) * (size_t)counts[i]);
-                    int nc = mtrh_chain(recs + p, counts[i], chain);
-                    mtrh_print_chain(stdout, &reads[i], recs + p, chain, nc, 0);
-                    free(chain);
-                }
-                p += counts[i];
-                mtrh_read_free(&reads[i]);
-            }
-        } else {
-            /* -a: chain every read first, then ONE device call aligns all reported repeats of the batch (the batch is
-             * still resident), then print in input order */
-            int *chains = (int *)malloc(sizeof(int) * (size_t)(nrec > 0 ? nrec : 1));
-            int *nchain = (int *)calloc((size_t)n, sizeof(int));
-            int64_t *cfirst = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
-            int64_t p = 0, ntask = 0;
-            for (int i = 0; i < n; i++) {
-                cfirst[i] = ntask;
-                if (counts[i] > 0) { nchain[i] = mtrh_chain(recs + p, counts[i], chains + p); ntask += nchain[i]; }
-                p += counts[i];
-            }
-            int32_t *t_read = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ntask > 0 ? ntask : 1));
-            mtr_record *t_rec = (mtr_record *)malloc(sizeof(mtr_record) * (size_t)(ntask > 0 ? ntask : 1));
-            if (!chains || !nchain || !cfirst || !t_read || !t_rec) { fprintf(stderr, "cannot allocate the alignment tasks\n"); exit(EXIT_FAILURE); }
-            p = 0;
-            for (int i = 0; i < n; i++) {
-                for (int t = 0; t < nchain[i]; t++) { t_read[cfirst[i] + t] = i; t_rec[cfirst[i] + t] = recs[p + chains[p + t]]; }
-                p += counts[i];
-            }
-            uint8_t *ops = NULL; int64_t *ooff = NULL; int32_t *ends = NULL;
-            st = mtr_alignments(ctx, (int32_t)ntask, t_read, t_rec, &ops, &ooff, &ends);
-            if (st != MTR_OK) { fprintf(stderr, "%s\n", mtr_last_error(ctx)); exit(EXIT_FAILURE); }
-            p = 0;
-            for (int i = 0; i < n; i++) {
-                if (nchain[i] > 0) mtrh_print_chain_ops(stdout, &reads[i], recs + p, chains + p, nchain[i], ops, ooff, ends, cfirst[i]);
-                p += counts[i];
-                mtrh_read_free(&reads[i]);
-            }
-            free(ops); free(ooff); free(ends); free(chains); free(nchain); free(cfirst); free(t_read); free(t_rec);
+        st = mtr_upload_batch(ctx, b->bases, b->offs, b->lens, b->n);
+        if (st == MTR_OK) st = mtr_run_resident_async(ctx);
+        if (st != MTR_OK) {                       /* like the reference: everything before the failing batch is reported first */
+            if (prev) finish_batch(&run, prev_ctx, prev);
+            fflush(stdout); fprintf(stderr, "%s\n", mtr_last_error(ctx)); exit(EXIT_FAILURE);
         }
-        t_chain += now() - tc;
-        mtr_free_results(recs, counts);
-        ingest_release(&ing, b);
-        t_mark = now();
+        run.t_submit += now() - t_mark;
+        if (prev) { finish_batch(&run, prev_ctx, prev); ingest_release(&ing, prev); }
+        prev = b; prev_ctx = ctx;
     }
+    if (prev) { finish_batch(&run, prev_ctx, prev); ingest_release(&ing, prev); }
     ingest_stop(&ing);
-    if (host_timing) fprintf(stderr, "[host] waiting for the FASTA thread %.3f s, mtr_process_batch %.3f s (kernel %.3f s), chain+print %.3f s\n", t_wait, t_proc, t_k1 + t_k2, t_chain);
+    const double t_k1 = 0, t_k2 = run.t_kernel, t_chain = run.t_chain; const long long queries = run.queries;
+    if (host_timing) fprintf(stderr, "[host] waiting for the FASTA thread %.3f s, pack+upload+launch %.3f s, waiting for the device + fetch %.3f s (kernels %.3f s), chain+print %.3f s\n",
+                             run.t_wait, run.t_submit, run.t_fetch, run.t_kernel, run.t_chain);
     mtrh_fasta_close(fa);
-    mtr_destroy(ctx);
+    mtr_destroy(ctxs[0]); mtr_destroy(ctxs[1]);
     if (print_time) {                             /* the reference's -c block (main.c:108-121) */
         fprintf(stderr, "Computation time\n");
         fprintf(stderr, "%f\tall\n", now() - t_all);

@@ -4,9 +4,12 @@
 //   packed   2 bit/base, MSB first, every read word-aligned and followed by 3 zero words (so that the
 //            reference's one-past-the-window accesses org[L], org[L+1] read 'A' = 0: isolated semantics)
 //   woff/lens/order   per read: word offset, length, processing order (longest first: work balance)
-//   ranges   per read a slice [r_off, r_off + L/2+64) of start/end/w/DI-bits written by K1, read by K2
-//   records  per read max_rec fixed slots written by K2, compacted on the device before the copy back
+//   ranges   per read a slice [r_off, r_off + L/2+64) of start/end/w/DI-bits written by the range phase, read by the unit phase
+//   records  per read max_rec fixed slots written by the unit phase, compacted on the device before the copy back
 //   scratch  one slice per resident wavefront, sized for the longest read of the batch (K1Layout/K2Layout)
+// Two ways through a batch (mtr_run_resident): one wavefront per read (mtr_k_reads), or, for batches that cannot fill
+// the chip, the range-parallel mode (launch_split: ranges kernel(s), one work item per range, replay).
+// Batch buffers are kept between batches and only grow.
 // There is no CPU path: every entry point needs the HIP device the context was created on.
 #include <hip/hip_runtime.h>
 #include <algorithm>

@@ -73,6 +73,11 @@ struct mtr_ctx {
     int32_t *d_item_read = nullptr, *d_item_idx = nullptr, *d_cand_flag = nullptr; int64_t *d_item_off = nullptr; DevRecord *d_cand = nullptr;
     int64_t item_cap = 0; bool last_split = false;
     std::vector<std::pair<void *, size_t>> caps;       // (address of the pointer member, bytes allocated)
+    // reads that found more records than their max_rec slots are run again with room for all of them (resolve_overflow)
+    std::vector<int32_t> ovf_reads; int ovf_cap = 0;
+    DevRecord *d_ovf_records = nullptr; int64_t *d_rec_base = nullptr; int32_t *d_ovf_order = nullptr;
+    const DevRecord **d_src = nullptr;                 // per read: where its records are (compaction)
+    bool sub_active = false;                           // launch_reads works on ovf_reads with the overflow buffers
     mtr_kernel_time kt[2] = { { 0, 0 }, { 0, 0 } };
     unsigned long long counters[CNT_N] = { 0 };
     bool ran = false, pending = false;
@@ -122,6 +127,7 @@ static void release_batch_buffers(mtr_ctx *ctx)
     dfree(ctx->d_packed); dfree(ctx->d_woff); dfree(ctx->d_lens); dfree(ctx->d_order);
     dfree(ctx->d_roff); dfree(ctx->d_rcount); dfree(ctx->d_rstart); dfree(ctx->d_rend); dfree(ctx->d_rw); dfree(ctx->d_rdi);
     dfree(ctx->d_records); dfree(ctx->d_reccount); dfree(ctx->d_recoff); dfree(ctx->d_out);
+    dfree(ctx->d_ovf_records); dfree(ctx->d_rec_base); dfree(ctx->d_ovf_order); dfree(ctx->d_src);
     dfree(ctx->d_item_read); dfree(ctx->d_item_idx); dfree(ctx->d_cand_flag); dfree(ctx->d_item_off); dfree(ctx->d_cand); ctx->item_cap = 0;
     ctx->caps.clear();
 }
@@ -255,6 +261,7 @@ extern "C" mtr_status mtr_upload_batch(mtr_ctx *ctx, const uint8_t *bases, const
 static BatchView view(const mtr_ctx *ctx)
 {
     BatchView b; b.packed = ctx->d_packed; b.woff = ctx->d_woff; b.lens = ctx->d_lens; b.order = ctx->d_order; b.n_reads = ctx->n_reads;
+    if (ctx->sub_active) { b.order = ctx->d_ovf_order; b.n_reads = (int32_t)ctx->ovf_reads.size(); }
     return b;
 }
 
@@ -292,7 +299,7 @@ static mtr_status launch_k1(mtr_ctx *ctx)
     size_t total = 0;
     int waves = pick_waves(ctx, ctx->n_reads, waves_per_cu(), y.total, &total);
     mtr_status s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;
-    K1Args a; k1_args(ctx, a, y.total);
+    K1Args a{}; k1_args(ctx, a, y.total);
     HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     hipLaunchKernelGGL(mtr_k1_ranges, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a);
@@ -327,7 +334,7 @@ static mtr_status launch_k1_parts(mtr_ctx *ctx)
         HIPCHK(hipMemcpyAsync(ctx->d_item_read, iread.data(), items * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->d_item_idx, ipass.data(), items * 4, hipMemcpyHostToDevice, ctx->stream));
     }
-    K1Args a; k1_args(ctx, a, y.total);
+    K1Args a{}; k1_args(ctx, a, y.total);
     const int slots = ctx->n_cu * waves_per_cu();
     HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
     hipLaunchKernelGGL(mtr_k1_part, dim3((unsigned)std::min(n, slots)), dim3(64), 0, ctx->stream, a, (int)K1_CODES, (const int32_t *)nullptr, (const int32_t *)nullptr, n);
@@ -352,12 +359,13 @@ static mtr_status launch_reads(mtr_ctx *ctx)
     size_t total = 0;
     int waves = pick_waves(ctx, ctx->n_reads, waves_per_cu(), per_wave, &total);
     mtr_status s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;
-    K1Args a1; k1_args(ctx, a1, per_wave);
-    K2Args a;
+    K1Args a1{}; k1_args(ctx, a1, per_wave);
+    K2Args a{};
     a.b = view(ctx); a.min_match_ratio = ctx->min_ratio; a.Lmax = ctx->Lmax;
     a.scratch = ctx->d_scratch; a.scratch_per_wave = per_wave;
     a.r_count = ctx->d_rcount; a.r_off = ctx->d_roff; a.r_start = ctx->d_rstart; a.r_end = ctx->d_rend; a.r_w = ctx->d_rw;
-    a.records = ctx->d_records; a.max_rec_per_read = ctx->max_rec; a.rec_count = ctx->d_reccount;
+    a.records = ctx->d_records; a.max_rec_per_read = ctx->max_rec; a.rec_count = ctx->d_reccount; a.rec_base = nullptr;
+    if (ctx->sub_active) { a.records = ctx->d_ovf_records; a.max_rec_per_read = ctx->ovf_cap; a.rec_base = ctx->d_rec_base; }
     a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
     a.trace = ctx->d_trace; a.trace_cap = ctx->trace_cap; a.trace_n = ctx->d_trace_n;
     a.trace_mask = getenv("MTR_TRACE_MASK") ? (int32_t)strtol(getenv("MTR_TRACE_MASK"), nullptr, 0) : -1;
@@ -419,16 +427,16 @@ static mtr_status launch_split(mtr_ctx *ctx)
     size_t total = 0;
     const int waves = pick_waves(ctx, (int)std::max<int64_t>(items, 1), waves_per_cu(), y2.total, &total);
     s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;
-    K2Args a;
+    K2Args a{};
     a.b = view(ctx); a.min_match_ratio = ctx->min_ratio; a.Lmax = ctx->Lmax;
     a.scratch = ctx->d_scratch; a.scratch_per_wave = y2.total;
     a.r_count = ctx->d_rcount; a.r_off = ctx->d_roff; a.r_start = ctx->d_rstart; a.r_end = ctx->d_rend; a.r_w = ctx->d_rw;
-    a.records = ctx->d_records; a.max_rec_per_read = ctx->max_rec; a.rec_count = ctx->d_reccount;
+    a.records = ctx->d_records; a.max_rec_per_read = ctx->max_rec; a.rec_count = ctx->d_reccount; a.rec_base = nullptr;
     a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
     a.trace = ctx->d_trace; a.trace_cap = ctx->trace_cap; a.trace_n = ctx->d_trace_n;
     a.trace_mask = getenv("MTR_TRACE_MASK") ? (int32_t)strtol(getenv("MTR_TRACE_MASK"), nullptr, 0) : -1;
     a.dp16_max_rows = dp16_max_rows();
-    SplitArgs sp;
+    SplitArgs sp{};
     sp.item_read = ctx->d_item_read; sp.item_idx = ctx->d_item_idx; sp.item_off = ctx->d_item_off; sp.n_items = (int32_t)items;
     sp.cand = ctx->d_cand; sp.cand_flag = ctx->d_cand_flag;
     HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
@@ -441,6 +449,34 @@ static mtr_status launch_split(mtr_ctx *ctx)
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
     return MTR_OK;
+}
+
+// A read gets max_rec = 16 + Lmax/100 record slots; the kernels count the records of a read that found more (about one
+// read in 10^5 of the synthetic sets) without storing them.  Such reads are run once more, alone, with exactly the room
+// they need (the ranges are recomputed: the unit phase prunes them in place); the compaction then takes their
+// records from the second buffer.  The reference has no such limit (std::set).
+static mtr_status resolve_overflow(mtr_ctx *ctx)
+{
+    const int n = ctx->n_reads;
+    std::vector<int32_t> cnt((size_t)n);
+    HIPCHK(copy_sync(ctx, cnt.data(), ctx->d_reccount, (size_t)n * 4, hipMemcpyDeviceToHost));
+    ctx->ovf_reads.clear(); ctx->ovf_cap = 0;
+    for (int i = 0; i < n; i++) if (cnt[(size_t)i] > ctx->max_rec) { ctx->ovf_reads.push_back(i); ctx->ovf_cap = std::max(ctx->ovf_cap, (int)cnt[(size_t)i]); }
+    if (ctx->ovf_reads.empty()) return MTR_OK;
+    const size_t m = ctx->ovf_reads.size();
+    DBG("resolve_overflow: %zu reads found more than %d records (max %d): running them again", m, ctx->max_rec, ctx->ovf_cap);
+    std::vector<int64_t> base((size_t)n, 0);
+    for (size_t k = 0; k < m; k++) base[(size_t)ctx->ovf_reads[k]] = (int64_t)k * ctx->ovf_cap;
+    HIPCHK(ensure_dev(ctx, ctx->d_ovf_records, m * (size_t)ctx->ovf_cap * sizeof(DevRecord)));
+    HIPCHK(ensure_dev(ctx, ctx->d_rec_base, (size_t)n * 8)); HIPCHK(ensure_dev(ctx, ctx->d_ovf_order, m * 4));
+    HIPCHK(hipMemcpyAsync(ctx->d_rec_base, base.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_ovf_order, ctx->ovf_reads.data(), m * 4, hipMemcpyHostToDevice, ctx->stream));
+    ctx->sub_active = true;
+    mtr_status s = launch_reads(ctx);                   // one wavefront per read; events ev[2..3] are re-recorded, the
+    ctx->sub_active = false;                            // kernel time reported stays the first run's (read before)
+    if (s != MTR_OK) return s;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return check_status(ctx);
 }
 
 extern "C" mtr_status mtr_run_resident_async(mtr_ctx *ctx)
@@ -469,7 +505,8 @@ extern "C" mtr_status mtr_wait(mtr_ctx *ctx)
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->kt[1].ms = ms; ctx->kt[1].launches = 1;
     HIPCHK(copy_sync(ctx, ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
     ctx->ran = true;
-    return check_status(ctx);
+    { mtr_status st = check_status(ctx); if (st != MTR_OK) return st; }
+    return resolve_overflow(ctx);
 }
 
 extern "C" mtr_status mtr_run_resident(mtr_ctx *ctx)
@@ -478,13 +515,29 @@ extern "C" mtr_status mtr_run_resident(mtr_ctx *ctx)
     return mtr_wait(ctx);
 }
 
-__global__ void mtr_k_compact(const DevRecord *in, const int32_t *cnt, const int64_t *off, int max_rec, int n_reads, DevRecord *out)
+// device array of per-read record sources for the compaction, or nullptr when every read's records are in its own slots
+static mtr_status record_sources(mtr_ctx *ctx, const DevRecord *const **out)
 {
-    // one block per read; records are copied as 16-byte words
+    *out = nullptr;
+    if (ctx->ovf_reads.empty()) return MTR_OK;
+    const int n = ctx->n_reads;
+    std::vector<const DevRecord *> src((size_t)n);
+    for (int i = 0; i < n; i++) src[(size_t)i] = ctx->d_records + (size_t)i * (size_t)ctx->max_rec;
+    for (size_t k = 0; k < ctx->ovf_reads.size(); k++) src[(size_t)ctx->ovf_reads[k]] = ctx->d_ovf_records + k * (size_t)ctx->ovf_cap;
+    HIPCHK(ensure_dev(ctx, ctx->d_src, (size_t)n * sizeof(void *)));
+    HIPCHK(copy_sync(ctx, ctx->d_src, src.data(), (size_t)n * sizeof(void *), hipMemcpyHostToDevice));
+    *out = ctx->d_src;
+    return MTR_OK;
+}
+
+__global__ void mtr_k_compact(const DevRecord *in, const DevRecord *const *src_of, const int32_t *cnt, const int64_t *off, int max_rec, int n_reads, DevRecord *out)
+{
+    // one block per read; records are copied as 16-byte words.  src_of (optional) = where each read's records are
+    // (reads that were run again with more slots have theirs in the overflow buffer)
     int rd = blockIdx.x;
     if (rd >= n_reads) return;
     int c = cnt[rd];
-    const uint4 *src = (const uint4 *)(in + (size_t)rd * (size_t)max_rec);
+    const uint4 *src = (const uint4 *)(src_of ? src_of[rd] : in + (size_t)rd * (size_t)max_rec);
     uint4 *dst = (uint4 *)(out + off[rd]);
     size_t words = (size_t)c * sizeof(DevRecord) / 16;
     for (size_t t = threadIdx.x; t < words; t += blockDim.x) dst[t] = src[t];
@@ -510,7 +563,9 @@ extern "C" mtr_status mtr_fetch_results(mtr_ctx *ctx, mtr_record **out_records, 
         HIPCHK(ensure_dev(ctx, ctx->d_out, (size_t)total * sizeof(DevRecord)));
         DevRecord *d_out = ctx->d_out;
         HIPCHK(hipMemcpyAsync(d_off, off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(mtr_k_compact, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->d_records, ctx->d_reccount, d_off, ctx->max_rec, n, d_out);
+        const DevRecord *const *srcs = nullptr;
+        { mtr_status st = record_sources(ctx, &srcs); if (st != MTR_OK) { free(counts); free(recs); return st; } }
+        hipLaunchKernelGGL(mtr_k_compact, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->d_records, srcs, ctx->d_reccount, d_off, ctx->max_rec, n, d_out);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(recs, d_out, (size_t)total * sizeof(DevRecord), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -536,7 +591,9 @@ extern "C" mtr_status mtr_export_records_device(mtr_ctx *ctx, void *d_dst, int64
     if (!d_dst || off[(size_t)n] > capacity_records) { ctx->err = "destination holds " + std::to_string(capacity_records) + " records, " + std::to_string(off[(size_t)n]) + " needed"; return MTR_ERR_OVERFLOW; }
     int64_t *d_off = ctx->d_recoff;
     HIPCHK(hipMemcpyAsync(d_off, off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(mtr_k_compact, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->d_records, ctx->d_reccount, d_off, ctx->max_rec, n, (DevRecord *)d_dst);
+    const DevRecord *const *srcs = nullptr;
+    { mtr_status st = record_sources(ctx, &srcs); if (st != MTR_OK) return st; }
+    hipLaunchKernelGGL(mtr_k_compact, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->d_records, srcs, ctx->d_reccount, d_off, ctx->max_rec, n, (DevRecord *)d_dst);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return MTR_OK;
@@ -629,7 +686,7 @@ extern "C" mtr_status mtr_test_wrap_dp(mtr_ctx *ctx, int32_t n_tasks, const int3
     HIPCHK(copy_sync(ctx, d_qe, query_end, nt * 4, hipMemcpyHostToDevice)); HIPCHK(copy_sync(ctx, d_g, gain, nt * 4, hipMemcpyHostToDevice));
     HIPCHK(copy_sync(ctx, d_m, mismatch, nt * 4, hipMemcpyHostToDevice)); HIPCHK(copy_sync(ctx, d_d, indel, nt * 4, hipMemcpyHostToDevice));
     HIPCHK(copy_sync(ctx, d_uo, unit_off, (nt + 1) * 4, hipMemcpyHostToDevice)); HIPCHK(copy_sync(ctx, d_units, units, (size_t)unit_off[n_tasks], hipMemcpyHostToDevice));
-    DpTestArgs a;
+    DpTestArgs a{};
     a.b = view(ctx); a.n_tasks = n_tasks; a.read_idx = d_rd; a.qs = d_qs; a.qe = d_qe; a.units = d_units; a.unit_off = d_uo;
     a.gain = d_g; a.mism = d_m; a.indel = d_d; a.out8 = d_out; a.scratch = ctx->d_scratch; a.scratch_per_wave = per_wave; a.cells_cap = cells;
     a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters; a.dp16_max_rows = dp16_max_rows();
@@ -695,7 +752,7 @@ extern "C" mtr_status mtr_alignments(mtr_ctx *ctx, int32_t n, const int32_t *rea
     ALN_CHK(hipMemcpyAsync(d_i32, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     ALN_CHK(hipMemcpyAsync(d_units, units.data(), units.size(), hipMemcpyHostToDevice, ctx->stream));
     ALN_CHK(hipMemcpyAsync(d_off, cap_off.data(), (nt + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    AlignArgs a;
+    AlignArgs a{};
     a.b = view(ctx); a.n_tasks = n;
     a.read_idx = d_i32; a.rep_start = d_i32 + nt; a.rep_end = d_i32 + 2 * nt; a.gain = d_i32 + 3 * nt; a.mism = d_i32 + 4 * nt; a.indel = d_i32 + 5 * nt;
     a.unit_off = d_i32 + 6 * nt; a.units = d_units;

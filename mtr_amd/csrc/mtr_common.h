@@ -187,7 +187,8 @@ struct K2Args {
     uint8_t *scratch; size_t scratch_per_wave;
     const int32_t *r_count; const int64_t *r_off;
     const int32_t *r_start; int32_t *r_end; const int32_t *r_w;    // r_end is overwritten (-1 = pruned)
-    DevRecord *records; int32_t max_rec_per_read; int32_t *rec_count;
+    DevRecord *records; int32_t max_rec_per_read; int32_t *rec_count;   // rec_count = records FOUND (may exceed the slots: the host reruns such reads)
+    const int64_t *rec_base;       // slot index of read rd's first record, or nullptr = rd * max_rec_per_read
     int32_t *status; unsigned int *work_counter; unsigned long long *counters;
     int32_t *trace; int32_t trace_cap; unsigned int *trace_n; int32_t trace_mask;   // bit t = record events of type t
     int32_t dp16_max_rows;         // DPs of up to this many rows may use the 16-bit kernels (tests set 0 to force the 32-bit ones)

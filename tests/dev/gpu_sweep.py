@@ -21,13 +21,16 @@ def main():
     import mtr_amd
     bad_total = 0
     with ProcessPoolExecutor(max_workers=12) as pool:
-        for cfg, seed, manhattan in (("headline2k", 101, True), ("c4", 102, True), ("c2", 103, True), ("headline2k", 104, False), ("c4", 105, False)):
+        plan = (("headline2k", 101, True), ("c4", 102, True), ("c2", 103, True), ("headline2k", 104, False), ("c4", 105, False))
+        if len(sys.argv) > 2:                               # one config at full size, e.g. "100000 c4" = BASELINE config 4
+            plan = ((sys.argv[2], 4, True),)
+        for cfg, seed, manhattan in plan:
             reads = [c for _, c in synth.make_reads(cfg, n if manhattan else n // 3, seed)]
             chunks = [reads[i:i + 100] for i in range(0, len(reads), 100)]
             t0 = time.time()
             want = [w for ch in pool.map(oracle_chunk, [(manhattan, c) for c in chunks]) for w in ch]
             t_or = time.time() - t0
-            for split in ("0", "1"):
+            for split in (("0",) if len(reads) > 20000 else ("0", "1")):
                 os.environ["MTR_SPLIT"] = split
                 eng = mtr_amd.Engine(manhattan=manhattan)
                 t0 = time.time(); got = eng.process(reads); t_gpu = time.time() - t0

@@ -277,3 +277,21 @@ def test_range_parallel_mode_golden(monkeypatch):
     assert checked >= 5
     for e in engines.values():
         e.close()
+
+
+def test_more_records_than_slots(eng, oracle):
+    """A read made of many short distinct repeats reports more records than its 16 + Lmax/100 slots: the library runs
+    such reads again with room for all of them (resolve_overflow) - the reference has no limit."""
+    rng = np.random.RandomState(31)
+    parts = []
+    for _ in range(70):
+        u = rng.randint(0, 4, size=int(rng.randint(3, 9))).astype(np.uint8)
+        parts.append(np.tile(u, 9)); parts.append(rng.randint(0, 4, size=6).astype(np.uint8))
+    crowded = np.concatenate(parts)
+    reads = [c for _, c in synth.make_reads("c2", 5, 77)] + [crowded] + [c for _, c in synth.make_reads("c2", 5, 78)]
+    got = eng.process(reads)
+    want = [oracle.process(c) for c in reads]
+    slots = 16 + max(len(r) for r in reads) // 100
+    assert len(want[5]) > slots, f"the crowded read should overflow its {slots} slots, it reports {len(want[5])}"
+    for i in range(len(reads)):
+        assert [tuple(r) for r in got[i]] == want[i], _diff_msg(i, want[i], [tuple(r) for r in got[i]])

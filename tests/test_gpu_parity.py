@@ -295,3 +295,24 @@ def test_more_records_than_slots(eng, oracle):
     assert len(want[5]) > slots, f"the crowded read should overflow its {slots} slots, it reports {len(want[5])}"
     for i in range(len(reads)):
         assert [tuple(r) for r in got[i]] == want[i], _diff_msg(i, want[i], [tuple(r) for r in got[i]])
+
+
+def _oracle_chunk(reads):
+    from tests.oracle_binding import Oracle
+    o = Oracle()
+    out = [o.process(r) for r in reads]
+    o.close()
+    return out
+
+
+def test_config4_mixed_lengths_every_read(eng):
+    """BASELINE config 4 shape (units of 50..200 bases, mixed read lengths), 10 000 reads, EVERY read against the oracle
+    (run in a process pool); one wavefront per read (the batch is larger than the range-parallel threshold)."""
+    from concurrent.futures import ProcessPoolExecutor
+    reads = [c for _, c in synth.make_reads("c4", 10000, 44)]
+    got = eng.process(reads)
+    chunks = [reads[i:i + 250] for i in range(0, len(reads), 250)]
+    with ProcessPoolExecutor(max_workers=8) as pool:
+        want = [w for ch in pool.map(_oracle_chunk, chunks) for w in ch]
+    bad = [i for i in range(len(reads)) if [tuple(r) for r in got[i]] != want[i]]
+    assert not bad, f"{len(bad)} of {len(reads)} reads differ, first: " + _diff_msg(bad[0], want[bad[0]], [tuple(r) for r in got[bad[0]]])

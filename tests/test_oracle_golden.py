@@ -68,6 +68,16 @@ APPENDIX_C = {
     ("10_50", "p"): "6e28d7cd0bd30975ecfc5e149c6b1efa", ("10_50", "a"): "0ee9584f80fe373c771cc3cac719654f",
     ("2_5_10_20_set", "default"): "9bdd2886b2ab2c13234e1b8e580f6b49", ("20_50", "a"): "561f1732f894bb1343f57e1aa793fa5e",
     ("5_20", "p"): "ead507e994e862be4a711172f7ea5ed6", ("3_50", "default"): "cc7cae93b0fb6ff07bdc2896510fd7b6",
+    # the four long files (90-140 kb): columns default, -p, -a of the same table
+    ("2_5_10_20_50_100_200_set", "default"): "dc4511cab46ccf31f1de08b884f25cfc",
+    ("2_5_10_20_50_100_200_set", "p"): "7440a6cfef00cd8f92f5c55957e840ca",
+    ("2_5_10_20_50_100_200_set", "a"): "114f1cfadce9c15492c10628639d62b2",
+    ("worm_chrI", "default"): "c69cc8326939f646bf2ead406f25dd30", ("worm_chrI", "p"): "736bd76c00874ba91064cc91e33b7760",
+    ("worm_chrI", "a"): "ca9d440960a787523fe05d0dda0b6a53",
+    ("worm_chrII_2", "default"): "fac1ee79765d5a0deb16bb757d8e8f3b", ("worm_chrII_2", "p"): "101d8da4b99cc55cb18864f51b879679",
+    ("worm_chrII_2", "a"): "aebaa788f1dd5f2aa78a07538723ee1b",
+    ("worm_chrII_1", "default"): "1f2716d22ae66304f4311b725c874592", ("worm_chrII_1", "p"): "9a0796754e8ae4ad3bfe2dcbd66effae",
+    ("worm_chrII_1", "a"): "47582116b5afb41bf38b133d90dbed34",
 }
 
 

@@ -79,6 +79,23 @@ def make_reads(config: str, n_reads: int | None = None, seed: int | None = None)
     return reads
 
 
+def make_mixed_file(n_reads: int, seed: int, max_len: int = 12000):
+    """Reads of widely different lengths (200 b .. max_len) in one file, the repeat anywhere including flush with
+    either end: the input on which the reference's results depend on the ORDER of the reads —
+    used by the tests of the file-order mode."""
+    rng = np.random.RandomState(seed)
+    reads = []
+    for i in range(n_reads):
+        u = int(rng.choice([2, 3, 5, 7, 12, 20, 33, 50, 100, 150]))
+        copies = int(rng.randint(4, 60))
+        total = int(np.exp(rng.uniform(np.log(200), np.log(max_len))))
+        room = max(0, total - u * copies)
+        pre = int(rng.randint(0, room + 1)) if rng.randint(0, 4) else (0 if rng.randint(0, 2) else room)
+        codes, _ = make_read(rng, u, copies, pre, room - pre)
+        reads.append((f"m{i}", codes))
+    return reads
+
+
 def write_fasta(path: str, reads) -> None:
     with open(path, "wb") as fh:
         for rid, codes in reads:

@@ -47,6 +47,9 @@ struct mtro_ctx {
     int level;
     mtro_stats st;
     int64_t undefined_hits;
+    int file_order;     /* 1 = the reference's own behaviour on a multi-read file: org[] and wrand[] are process-wide
+                         * (handle_one_file.c:85, mTR.h:65-67) and keep what earlier reads left beyond the part the
+                         * current read rewrites (leak A, and H2) */
     /* per-read buffers */
     int L;
     int *org;           /* L+2 entries, org[L]=org[L+1]=0 (isolated semantics) */
@@ -132,6 +135,16 @@ void mtro_destroy(mtro_ctx *c)
     free(c);
 }
 void mtro_set_capture(mtro_ctx *c, FILE *cap, int level) { c->cap = cap; c->level = level; }
+#define FILE_ORDER_WRAND ((size_t)MTRO_MAX_INPUT_LENGTH * 2 + (size_t)MTRO_MAX_INPUT_LENGTH / 2)
+void mtro_set_file_order(mtro_ctx *c, int on)
+{   /* the buffers become process-wide, zero at the start like the reference's freshly mapped malloc */
+    c->file_order = on;
+    if (!on) return;
+    free(c->org); free(c->wrand);
+    c->org = (int *)calloc((size_t)MTRO_MAX_INPUT_LENGTH + 4, sizeof(int));
+    c->wrand_cap = FILE_ORDER_WRAND; c->wrand = (int *)calloc(c->wrand_cap, sizeof(int));
+    if (!c->org || !c->wrand) { fprintf(stderr, "mtr_oracle: out of memory\n"); exit(EXIT_FAILURE); }
+}
 const mtro_stats *mtro_get_stats(const mtro_ctx *c) { return &c->st; }
 void mtro_reset_stats(mtro_ctx *c) { memset(&c->st, 0, sizeof(c->st)); }
 
@@ -145,7 +158,7 @@ void mtro_reset_stats(mtro_ctx *c) { memset(&c->st, 0, sizeof(c->st)); }
  * zeros (isolated semantics: fresh calloc). */
 static void build_wrand(mtro_ctx *c, int k, int L, int r)
 {
-    memset(c->wrand, 0, c->wrand_cap * sizeof(int));
+    if (!c->file_order) memset(c->wrand, 0, c->wrand_cap * sizeof(int));
     mt_t m; mt_seed(&m, 0);
     int *s = c->wrand;
     for (int i = 0; i < L + 4 * r && i < MTRO_MAX_INPUT_LENGTH; i++) s[i] = (int)(mt_next(&m) % 4);
@@ -744,6 +757,7 @@ static void ensure_read_buffers(mtro_ctx *c, int L, int r)
 static void load_read(mtro_ctx *c, const uint8_t *codes, int L)
 {
     c->L = L;
+    if (c->file_order) { for (int i = 0; i < L; i++) c->org[i] = codes[i]; return; }   /* handle_one_file.c:284-285 */
     c->org = (int *)xrealloc(c->org, ((size_t)L + 4) * sizeof(int));
     for (int i = 0; i < L; i++) c->org[i] = codes[i];
     c->org[L] = c->org[L + 1] = c->org[L + 2] = c->org[L + 3] = 0;

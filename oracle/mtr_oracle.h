@@ -49,6 +49,10 @@ mtro_ctx *mtro_create(int manhattan, float min_match_ratio);
 void      mtro_destroy(mtro_ctx *);
 /* capture stream in the JSONL format of oracle/ref_capture.c (NULL = off); level as there */
 void      mtro_set_capture(mtro_ctx *, FILE *cap, int level);
+/* on = the reference's behaviour on a multi-read file instead of isolated semantics: the reads must then be given
+ * in file order (results of a read depend on the longer reads before it).  Checked against the reference run on
+ * whole files (tests/test_oracle_golden.py, capture points G1..G4; stdout up to the heap-order chaining ties). */
+void      mtro_set_file_order(mtro_ctx *, int on);
 const mtro_stats *mtro_get_stats(const mtro_ctx *);
 void      mtro_reset_stats(mtro_ctx *);
 

@@ -1,7 +1,7 @@
 /*
  * mtr_oracle_cli — TEST INFRASTRUCTURE ONLY.  Same command line and stdout as reference mTR
  * (main.c:48-123), driven by the CPU restatement in mtr_oracle.c, one read at a time under isolated
- * semantics.  Extra flags: -l <level> -C <capture.jsonl> write the capture points in the format of
+ * semantics (-B: the reference's own behaviour on a multi-read file, mtro_set_file_order).  Extra flags: -l <level> -C <capture.jsonl> write the capture points in the format of
  * oracle/ref_capture.c; -S prints the work counters (DP cells, k-mer look-ups ...) to stderr.
  */
 #define _POSIX_C_SOURCE 200809L
@@ -13,11 +13,11 @@
 
 int main(int argc, char **argv)
 {
-    int print_alignment = 0, print_time = 0, manhattan = 1, level = 1, print_stats = 0;
+    int print_alignment = 0, print_time = 0, manhattan = 1, level = 1, print_stats = 0, file_order = 0;
     float min_ratio = 0.6f;
     const char *cap_path = NULL;
     int opt;
-    while ((opt = getopt(argc, argv, "acm:pl:C:S")) != -1) {
+    while ((opt = getopt(argc, argv, "acm:pl:C:SB")) != -1) {
         switch (opt) {
         case 'a': print_alignment = 1; break;
         case 'c': print_time = 1; break;
@@ -28,6 +28,7 @@ int main(int argc, char **argv)
         case 'l': level = atoi(optarg); break;
         case 'C': cap_path = optarg; break;
         case 'S': print_stats = 1; break;
+        case 'B': file_order = 1; break;
         default:
             fprintf(stderr, "mTR [-acp] [-m ratio] <fasta file name> \n");
             return EXIT_FAILURE;
@@ -38,6 +39,7 @@ int main(int argc, char **argv)
     char **ids; uint8_t **seqs; int *lens;
     int n = mtro_read_fasta(argv[optind], &ids, &seqs, &lens);
     mtro_ctx *c = mtro_create(manhattan, min_ratio);
+    if (file_order) mtro_set_file_order(c, 1);
     FILE *cap = NULL;
     if (cap_path) { cap = fopen(cap_path, "w"); if (!cap) { perror(cap_path); return EXIT_FAILURE; } mtro_set_capture(c, cap, level); }
     for (int i = 0; i < n; i++) {

@@ -65,6 +65,19 @@ def run_reference_isolated(fasta, flags=(), level=1, workers=8):
     return b"".join(o for o, _ in outs), b"".join(c for _, c in outs)
 
 
+def run_reference_whole_file(fasta, flags=(), level=1):
+    """The reference as its users run it: one process for the whole file.  Its results depend on the order of the
+    reads: leak A (stale tail of inputString_w_rand / orgInputString) shows in the capture stream,
+    leak B (std::set in heap-pointer order) only in which of two equal-score chains is printed."""
+    with tempfile.TemporaryDirectory(prefix="mtr_file_") as tmpdir:
+        cap = os.path.join(tmpdir, "cap.jsonl")
+        p = subprocess.run([REF_CAPTURE, *flags, "-l", str(level), fasta, cap], capture_output=True)
+        if p.returncode != 0:
+            raise RuntimeError(f"reference failed: {p.stderr.decode()[:500]}")
+        with open(cap, "rb") as fh:
+            return p.stdout, fh.read()
+
+
 def run_oracle(fasta, flags=(), level=1):
     with tempfile.NamedTemporaryFile(suffix=".jsonl", delete=False) as tf:
         cap = tf.name
@@ -98,16 +111,20 @@ def main():
     ap.add_argument("--cap", help="write reference capture JSONL here")
     ap.add_argument("--check", action="store_true", help="compare with oracle/mtr_oracle_cli")
     ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--file-order", action="store_true", help="the reference in ONE process for the whole file against the oracle's -B mode")
     a = ap.parse_args()
     flags = a.flags.split()
-    r_out, r_cap = run_reference_isolated(a.fasta, flags, a.level, a.workers)
+    if a.file_order:
+        r_out, r_cap = run_reference_whole_file(a.fasta, flags, a.level)
+    else:
+        r_out, r_cap = run_reference_isolated(a.fasta, flags, a.level, a.workers)
     if a.out:
         open(a.out, "wb").write(r_out)
     if a.cap:
         open(a.cap, "wb").write(r_cap)
     rc = 0
     if a.check:
-        o_out, o_cap = run_oracle(a.fasta, flags, a.level)
+        o_out, o_cap = run_oracle(a.fasta, flags + (["-B"] if a.file_order else []), a.level)
         for name, x, y in (("stdout", r_out, o_out), ("capture", r_cap, o_cap)):
             d = first_diff(x, y)
             n = x.count(b"\n")

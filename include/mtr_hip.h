@@ -100,6 +100,31 @@ mtr_status mtr_run_resident_async(mtr_ctx *ctx);
 mtr_status mtr_wait(mtr_ctx *ctx);
 mtr_status mtr_fetch_results(mtr_ctx *ctx, mtr_record **out_records, int32_t **out_counts, int64_t *out_total);
 
+/* File-order mode = the reference's own behaviour on a multi-read file (leak A, and H2) instead of
+ * isolated semantics.  The reference's inputString_w_rand and orgInputString live for the whole file
+ * (handle_one_file.c:85, mTR.h:65-67): the window look-ahead of a read (fill_directional_index.c:232) and the one-past
+ * reads of its DPs (wrap_around_DP.c:243-245) see what the most recent LONGER read left beyond the part the current
+ * read rewrites.  A mtr_file_state is the host shadow of that state for ONE file; give it the batches of the file in
+ * file order (any context, any batch size — the state carries over) through mtr_upload_batch_in_file instead of
+ * mtr_upload_batch, then run / fetch as usual.  Results then equal the reference run on the whole file at the lower
+ * edge (the arguments of insert_an_alignment_into_set, read after read); the printed chain can still differ where two
+ * chains tie, because the reference breaks those ties by heap address (chaining.cpp:201).  Reads no longer read
+ * preceded take the normal path; the others run their range phase with plain 1024-bin window histograms (slower).
+ * Shards of a file given to different GPUs need the state of the reads before the shard: feed those lengths/bases
+ * through mtr_file_state_skip. */
+typedef struct mtr_file_state mtr_file_state;
+mtr_status mtr_file_state_create(mtr_file_state **out);
+void       mtr_file_state_destroy(mtr_file_state *fs);
+mtr_status mtr_upload_batch_in_file(mtr_ctx *ctx, mtr_file_state *fs, const uint8_t *bases, const int64_t *offsets,
+                                    const int32_t *lens, int32_t n_reads);
+/* advance the state over reads that another context / GPU processes (same arguments as an upload, no device work) */
+mtr_status mtr_file_state_skip(mtr_file_state *fs, const uint8_t *bases, const int64_t *offsets, const int32_t *lens, int32_t n_reads);
+
+/* orgInputString[L] and [L+1] as read i of the resident batch found them: 0 under isolated semantics, in file-order mode
+ * the bases an earlier, longer read left there.  A repeat can end on them (wrap_around_DP.c:243-245), and a printer of
+ * the -a alignments (mtr_alignments) needs them for its top row. */
+mtr_status mtr_get_bases_after_read(const mtr_ctx *ctx, int32_t read_idx, uint8_t out[2]);
+
 /* Multi-GPU plumbing: compacts the records of the last run (read after read, insertion order) into
  * caller-owned DEVICE memory on the context's GPU (capacity in records) so that the caller can hand it
  * to RCCL without a host round trip; counts_host receives n_reads per-read counts. */

@@ -29,11 +29,42 @@ COUNTER_NAMES = ["dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_d
 EXPORTS = ["mtr_create", "mtr_destroy", "mtr_last_error", "mtr_abi_version", "mtr_process_batch", "mtr_free_results",
            "mtr_upload_batch", "mtr_run_resident", "mtr_fetch_results", "mtr_get_kernel_times", "mtr_get_counters",
            "mtr_test_ranges", "mtr_test_wrap_dp", "mtr_set_trace", "mtr_get_trace", "mtr_export_records_device",
-           "mtr_run_resident_async", "mtr_wait", "mtr_alignments"]
+           "mtr_run_resident_async", "mtr_wait", "mtr_alignments",
+           "mtr_file_state_create", "mtr_file_state_destroy", "mtr_upload_batch_in_file", "mtr_file_state_skip",
+           "mtr_get_bases_after_read"]
 
 
 class MtrError(RuntimeError):
     pass
+
+
+class FileState:
+    """mtr_file_state: host shadow of what the reads of ONE file leave behind for the reads after them (file-order mode)."""
+
+    def __init__(self):
+        self.lib = load_library()
+        h = C.c_void_p()
+        st = self.lib.mtr_file_state_create(C.byref(h))
+        if st != 0:
+            raise MtrError(f"mtr_file_state_create: {STATUS.get(st, st)}")
+        self.h = h
+
+    def skip(self, reads):
+        bases, offs, lens = _flatten(reads)
+        st = self.lib.mtr_file_state_skip(self.h, bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(reads))
+        if st != 0:
+            raise MtrError(f"mtr_file_state_skip: {STATUS.get(st, st)}")
+
+    def close(self):
+        if self.h:
+            self.lib.mtr_file_state_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class CRecord(C.Structure):
@@ -94,6 +125,14 @@ def load_library(path: str = LIB_PATH):
     lib.mtr_upload_batch.restype = C.c_int
     lib.mtr_run_resident.argtypes = [C.c_void_p]
     lib.mtr_run_resident.restype = C.c_int
+    lib.mtr_file_state_create.argtypes = [P(C.c_void_p)]
+    lib.mtr_file_state_create.restype = C.c_int
+    lib.mtr_file_state_destroy.argtypes = [C.c_void_p]
+    lib.mtr_file_state_destroy.restype = None
+    lib.mtr_upload_batch_in_file.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.mtr_upload_batch_in_file.restype = C.c_int
+    lib.mtr_file_state_skip.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.mtr_file_state_skip.restype = C.c_int
     lib.mtr_run_resident_async.argtypes = [C.c_void_p]
     lib.mtr_run_resident_async.restype = C.c_int
     lib.mtr_wait.argtypes = [C.c_void_p]
@@ -161,11 +200,22 @@ class Engine:
             raise MtrError(f"{what}: {STATUS.get(st, st)}: {self.lib.mtr_last_error(self.h).decode(errors='replace')}")
 
     # ---- the batch edge -------------------------------------------------------------------------------
-    def upload(self, reads: Sequence[np.ndarray]):
+    def upload(self, reads: Sequence[np.ndarray], file_state: "FileState | None" = None):
+        """file_state: the reads are the next reads of that file (file-order mode, mtr_upload_batch_in_file)"""
         bases, offs, lens = _flatten(reads)
         self._keep = (bases, offs, lens)
-        self._check(self.lib.mtr_upload_batch(self.h, bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(reads)), "mtr_upload_batch")
+        if file_state is None:
+            self._check(self.lib.mtr_upload_batch(self.h, bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(reads)), "mtr_upload_batch")
+        else:
+            self._check(self.lib.mtr_upload_batch_in_file(self.h, file_state.h, bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(reads)),
+                        "mtr_upload_batch_in_file")
         self.n_reads = len(reads)
+
+    def process_in_file(self, reads: Sequence[np.ndarray], file_state: "FileState") -> List[List[Record]]:
+        """the next reads of a file under the reference's whole-file behaviour (include/mtr_hip.h, file-order mode)"""
+        self.upload(reads, file_state)
+        self.run()
+        return self.fetch()
 
     def run(self):
         self._check(self.lib.mtr_run_resident(self.h), "mtr_run_resident")

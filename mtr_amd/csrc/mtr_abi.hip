@@ -78,10 +78,93 @@ struct mtr_ctx {
     DevRecord *d_ovf_records = nullptr; int64_t *d_rec_base = nullptr; int32_t *d_ovf_order = nullptr;
     const DevRecord **d_src = nullptr;                 // per read: where its records are (compaction)
     bool sub_active = false;                           // launch_reads works on ovf_reads with the overflow buffers
+    // file-order mode (mtr_upload_batch_in_file): per read the stale tail of the reference's inputString_w_rand
+    bool file_order = false; uint16_t *d_tail = nullptr; int64_t *d_tail_off = nullptr;
+    std::vector<uint8_t> after;                        // 2 per read: orgInputString[L], [L+1] (zeros unless file-order)
     mtr_kernel_time kt[2] = { { 0, 0 }, { 0, 0 } };
     unsigned long long counters[CNT_N] = { 0 };
     bool ran = false, pending = false;
 };
+
+// ---- file-order mode: the host shadow of the reference's process-wide buffers ---------------------------------------
+// The reference keeps inputString_w_rand and orgInputString for the whole file (handle_one_file.c:85, mTR.h:65-67).  A
+// read rewrites [0, E) of the first (E = max(L + 2r, min(L + 4r, 1e6)), fill_directional_index.c:137-169, three times:
+// k = 1, 3, 5, so it LEAVES the k = 5 encoding) and [0, L) of the second; the passes of the next read look up to
+// L + r + 2w - k (:232) and its DPs up to org[L + 1], i.e. into what the most recent LONGER read left there.
+// That state is a staircase: of all earlier reads only those longer than every read after them still show.
+struct mtr_file_state {
+    struct Entry { int32_t L = 0, r = 0; int64_t N = 0, n = 0, E = 0; std::vector<uint8_t> codes; };
+    std::vector<Entry> stairs;               // E (and L) strictly increasing from back() = most recent to front()
+    std::vector<uint8_t> mt;                 // the MT19937 base stream (same as the device's)
+    int64_t reads_seen = 0;
+    int raw(const Entry &e, int64_t q) const
+    {   // the buffer before the rolling encode, as k1_raw (k1_ranges.hip.inc)
+        if (q < e.r) return mt[(size_t)(e.N + q)];
+        if (q < e.r + e.L) return e.codes[(size_t)(q - e.r)];
+        if (q < e.n) return mt[(size_t)(e.N + e.r + (q - e.r - e.L))];
+        return mt[(size_t)q];                // q < N
+    }
+    int left_at(const Entry &e, int64_t p) const
+    {   // what the read left at p < E: the 5-mer code where one was formed (:162-168), else the raw entry
+        if (p < e.n - 4) { int v = 0; for (int t = 0; t < 5; t++) v = 4 * v + raw(e, p + t); return v; }
+        return raw(e, p);
+    }
+    static void geometry(int32_t L, Entry &e)
+    {
+        e.L = L; e.r = mtrc_rand_len(L); e.n = (int64_t)L + 2 * e.r;
+        e.N = std::min<int64_t>((int64_t)L + 4 * (int64_t)e.r, MTRC_MAX_INPUT_LENGTH);
+        e.E = std::max(e.N, e.n);
+    }
+    // the entries [E, reach) of inputString_w_rand as the NEXT read of length L finds them
+    void tail_for(int32_t L, std::vector<uint16_t> &out) const
+    {
+        Entry me; geometry(L, me);
+        int wtop = 0;
+        for (int w = MTRC_MIN_WINDOW; w <= MTRC_MAX_WINDOW && w < L / 2; w *= 2) wtop = w;
+        const int64_t reach = std::max<int64_t>((int64_t)L + me.r + 2 * wtop + 8, me.E);      // = ncode of k1_read
+        int64_t cur = me.E;
+        for (size_t k = stairs.size(); k-- > 0 && cur < reach; ) {
+            const Entry &e = stairs[k];
+            if (e.E <= cur) continue;
+            const int64_t end = std::min(e.E, reach);
+            for (int64_t p = cur; p < end; p++) out.push_back((uint16_t)left_at(e, p));
+            cur = end;
+        }
+    }
+    int org_at(int64_t p) const
+    {   // orgInputString[p] for p >= the length of the next read
+        for (size_t k = stairs.size(); k-- > 0; ) if (stairs[k].L > p) return stairs[k].codes[(size_t)p];
+        return 0;
+    }
+    void push(const uint8_t *codes, int32_t L)
+    {
+        Entry e; geometry(L, e);
+        while (!stairs.empty() && stairs.back().L <= L) stairs.pop_back();
+        e.codes.assign(codes, codes + L);
+        stairs.push_back(std::move(e));
+        reads_seen++;
+    }
+};
+
+extern "C" mtr_status mtr_file_state_create(mtr_file_state **out)
+{
+    if (!out) return MTR_ERR_BAD_ARG;
+    mtr_file_state *fs = new (std::nothrow) mtr_file_state();
+    if (!fs) { *out = nullptr; return MTR_ERR_OOM; }
+    mt_bases(fs->mt, (size_t)MTRC_MAX_INPUT_LENGTH + 2 * 100000 + 64);
+    *out = fs;
+    return MTR_OK;
+}
+extern "C" void mtr_file_state_destroy(mtr_file_state *fs) { delete fs; }
+extern "C" mtr_status mtr_file_state_skip(mtr_file_state *fs, const uint8_t *bases, const int64_t *offsets, const int32_t *lens, int32_t n)
+{
+    if (!fs || !bases || !offsets || !lens || n < 0) return MTR_ERR_BAD_ARG;
+    for (int i = 0; i < n; i++) {
+        if (lens[i] <= 0 || lens[i] > MTRC_MAX_SUPPORTED_LENGTH) return MTR_ERR_BAD_ARG;
+        fs->push(bases + offsets[i], lens[i]);
+    }
+    return MTR_OK;
+}
 
 // test knob: MTR_DP16_MAX_ROWS=0 sends every DP through the 32-bit kernels (the fallbacks of reads > 64 kb)
 static int dp16_max_rows() { const char *e = getenv("MTR_DP16_MAX_ROWS"); return e ? atoi(e) : 0x7fffffff; }
@@ -129,6 +212,7 @@ static void release_batch_buffers(mtr_ctx *ctx)
     dfree(ctx->d_records); dfree(ctx->d_reccount); dfree(ctx->d_recoff); dfree(ctx->d_out);
     dfree(ctx->d_ovf_records); dfree(ctx->d_rec_base); dfree(ctx->d_ovf_order); dfree(ctx->d_src);
     dfree(ctx->d_item_read); dfree(ctx->d_item_idx); dfree(ctx->d_cand_flag); dfree(ctx->d_item_off); dfree(ctx->d_cand); ctx->item_cap = 0;
+    dfree(ctx->d_tail); dfree(ctx->d_tail_off);
     ctx->caps.clear();
 }
 
@@ -209,7 +293,17 @@ static int pick_waves(mtr_ctx *ctx, int n_items, int per_cu, size_t per_wave, si
     return (int)waves;
 }
 
+static mtr_status upload_batch(mtr_ctx *ctx, mtr_file_state *fs, const uint8_t *bases, const int64_t *offsets, const int32_t *lens, int32_t n);
 extern "C" mtr_status mtr_upload_batch(mtr_ctx *ctx, const uint8_t *bases, const int64_t *offsets, const int32_t *lens, int32_t n)
+{
+    return upload_batch(ctx, nullptr, bases, offsets, lens, n);
+}
+extern "C" mtr_status mtr_upload_batch_in_file(mtr_ctx *ctx, mtr_file_state *fs, const uint8_t *bases, const int64_t *offsets, const int32_t *lens, int32_t n)
+{
+    if (!fs) { if (ctx) ctx->err = "null file state"; return MTR_ERR_BAD_ARG; }
+    return upload_batch(ctx, fs, bases, offsets, lens, n);
+}
+static mtr_status upload_batch(mtr_ctx *ctx, mtr_file_state *fs, const uint8_t *bases, const int64_t *offsets, const int32_t *lens, int32_t n)
 {
     if (!ctx) return MTR_ERR_BAD_ARG;
     if (!bases || !offsets || !lens || n <= 0) { ctx->err = "null input or n_reads <= 0"; return MTR_ERR_BAD_ARG; }
@@ -232,6 +326,24 @@ extern "C" mtr_status mtr_upload_batch(mtr_ctx *ctx, const uint8_t *bases, const
             w[p >> 4] |= (uint32_t)b[p] << (30 - 2 * (p & 15));
         }
     }
+    // file-order mode: in file order, what each read finds beyond its own part of the reference's two buffers
+    std::vector<uint16_t> tail; std::vector<int64_t> tail_off;
+    ctx->after.assign((size_t)n * 2, 0);
+    if (fs) {
+        tail_off.assign((size_t)n + 1, 0);
+        for (int i = 0; i < n; i++) {
+            fs->tail_for(lens[i], tail);
+            tail_off[(size_t)i + 1] = (int64_t)tail.size();
+            uint32_t *w = packed.data() + woff[(size_t)i];
+            for (int64_t p = lens[i]; p < (int64_t)lens[i] + 2; p++) {
+                const int b = fs->org_at(p);
+                ctx->after[(size_t)i * 2 + (size_t)(p - lens[i])] = (uint8_t)b;
+                w[p >> 4] |= (uint32_t)b << (30 - 2 * (int)(p & 15));
+            }
+            fs->push(bases + offsets[i], lens[i]);
+        }
+    }
+    ctx->file_order = fs != nullptr;
     std::vector<int32_t> order((size_t)n); std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });
     ctx->roff.assign((size_t)n + 1, 0);
@@ -254,6 +366,11 @@ extern "C" mtr_status mtr_upload_batch(mtr_ctx *ctx, const uint8_t *bases, const
     HIPCHK(hipMemcpyAsync(ctx->d_lens, lens, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_roff, ctx->roff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (fs) {
+        HIPCHK(ensure_dev(ctx, ctx->d_tail, std::max<size_t>(tail.size(), 1) * 2)); HIPCHK(ensure_dev(ctx, ctx->d_tail_off, ((size_t)n + 1) * 8));
+        if (!tail.empty()) HIPCHK(hipMemcpyAsync(ctx->d_tail, tail.data(), tail.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->d_tail_off, tail_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return MTR_OK;
 }
@@ -290,6 +407,7 @@ static void k1_args(mtr_ctx *ctx, K1Args &a, size_t per_wave)
     a.scratch = ctx->d_scratch; a.scratch_per_wave = per_wave;
     a.r_count = ctx->d_rcount; a.r_off = ctx->d_roff; a.r_start = ctx->d_rstart; a.r_end = ctx->d_rend; a.r_w = ctx->d_rw; a.r_di = ctx->d_rdi;
     a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
+    a.tail = ctx->file_order ? ctx->d_tail : nullptr; a.tail_off = ctx->file_order ? ctx->d_tail_off : nullptr;
 }
 
 // K1 alone (mtr_test_ranges)
@@ -351,16 +469,8 @@ static mtr_status launch_k1_parts(mtr_ctx *ctx)
     return MTR_OK;
 }
 
-// the per-read kernel: ranges (K1 code) and unit search / DP (K2 code) of a read by the same wavefront
-static mtr_status launch_reads(mtr_ctx *ctx)
+static void k2_args(mtr_ctx *ctx, K2Args &a, size_t per_wave)
 {
-    K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
-    const size_t per_wave = std::max(y1.total, y2.total);       // the two phases of a read use the arena one after the other
-    size_t total = 0;
-    int waves = pick_waves(ctx, ctx->n_reads, waves_per_cu(), per_wave, &total);
-    mtr_status s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;
-    K1Args a1{}; k1_args(ctx, a1, per_wave);
-    K2Args a{};
     a.b = view(ctx); a.min_match_ratio = ctx->min_ratio; a.Lmax = ctx->Lmax;
     a.scratch = ctx->d_scratch; a.scratch_per_wave = per_wave;
     a.r_count = ctx->d_rcount; a.r_off = ctx->d_roff; a.r_start = ctx->d_rstart; a.r_end = ctx->d_rend; a.r_w = ctx->d_rw;
@@ -370,6 +480,42 @@ static mtr_status launch_reads(mtr_ctx *ctx)
     a.trace = ctx->d_trace; a.trace_cap = ctx->trace_cap; a.trace_n = ctx->d_trace_n;
     a.trace_mask = getenv("MTR_TRACE_MASK") ? (int32_t)strtol(getenv("MTR_TRACE_MASK"), nullptr, 0) : -1;
     a.dp16_max_rows = dp16_max_rows();
+}
+
+// File-order mode with one wavefront per read: the range kernel (it reads the stale tails) and the unit kernel, each
+// with its own scratch layout over the same allocation.
+static mtr_status launch_file_order(mtr_ctx *ctx)
+{
+    K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
+    size_t t1 = 0, t2 = 0;
+    const int w1 = pick_waves(ctx, ctx->n_reads, waves_per_cu(), y1.total, &t1);
+    const int w2 = pick_waves(ctx, ctx->n_reads, waves_per_cu(), y2.total, &t2);
+    mtr_status s = ensure_scratch(ctx, std::max(t1, t2)); if (s != MTR_OK) return s;
+    K1Args a1{}; k1_args(ctx, a1, y1.total);
+    K2Args a{}; k2_args(ctx, a, y2.total);
+    HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_trace_n, 0, sizeof(unsigned), ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    hipLaunchKernelGGL(mtr_k1_ranges, dim3((unsigned)w1), dim3(64), 0, ctx->stream, a1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(mtr_k_units, dim3((unsigned)w2), dim3(64), 0, ctx->stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+    return MTR_OK;
+}
+
+// the per-read kernel: ranges (K1 code) and unit search / DP (K2 code) of a read by the same wavefront
+static mtr_status launch_reads(mtr_ctx *ctx)
+{
+    if (ctx->file_order) return launch_file_order(ctx);
+    K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
+    const size_t per_wave = std::max(y1.total, y2.total);       // the two phases of a read use the arena one after the other
+    size_t total = 0;
+    int waves = pick_waves(ctx, ctx->n_reads, waves_per_cu(), per_wave, &total);
+    mtr_status s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;
+    K1Args a1{}; k1_args(ctx, a1, per_wave);
+    K2Args a{}; k2_args(ctx, a, per_wave);
     HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_trace_n, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
@@ -608,6 +754,13 @@ extern "C" mtr_status mtr_process_batch(mtr_ctx *ctx, const uint8_t *bases, cons
 }
 
 extern "C" void mtr_free_results(mtr_record *records, int32_t *counts) { free(records); free(counts); }
+
+extern "C" mtr_status mtr_get_bases_after_read(const mtr_ctx *ctx, int32_t read_idx, uint8_t out[2])
+{
+    if (!ctx || !out || read_idx < 0 || read_idx >= ctx->n_reads || ctx->after.size() < (size_t)ctx->n_reads * 2) return MTR_ERR_BAD_ARG;
+    out[0] = ctx->after[(size_t)read_idx * 2]; out[1] = ctx->after[(size_t)read_idx * 2 + 1];
+    return MTR_OK;
+}
 
 extern "C" mtr_status mtr_get_kernel_times(const mtr_ctx *ctx, mtr_kernel_time *out, int32_t n)
 {

@@ -178,6 +178,10 @@ struct K1Args {
     int32_t *r_count; const int64_t *r_off;
     int32_t *r_start, *r_end, *r_w; uint64_t *r_di;
     int32_t *status; unsigned int *work_counter; unsigned long long *counters;
+    // file-order mode (mtr_upload_batch_in_file): what earlier, longer reads of the file left in the reference's
+    // process-wide inputString_w_rand beyond the part this read rewrites - tail[tail_off[rd] + (p - E)] is the entry at
+    // position p >= E = max(L + 2r, min(L + 4r, 1e6)); beyond the slice (and always when tail == nullptr): zero
+    const uint16_t *tail; const int64_t *tail_off;
 };
 
 struct K2Args {

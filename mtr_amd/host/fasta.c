@@ -63,7 +63,7 @@ static int next_read(mtrh_fasta *f, mtrh_read *out)
             if (!f->have_header) { f->have_header = 1; id = header_id(f->buf); continue; }
             f->pending_id = header_id(f->buf);
             if (n == 0) { f->done = 1; free(id); free(codes); return 0; }
-            out->id = id; out->codes = codes; out->len = (int32_t)n;
+            out->id = id; out->codes = codes; out->len = (int32_t)n; out->after[0] = out->after[1] = 0;
             return 1;
         }
         if (n + MTRH_BLK > cap) { cap = cap ? cap * 2 : 4096; if (cap < n + MTRH_BLK) cap = n + MTRH_BLK; codes = (uint8_t *)xrealloc(codes, cap); }
@@ -80,7 +80,7 @@ static int next_read(mtrh_fasta *f, mtrh_read *out)
     f->done = 1;
     if (n == 0) { free(id); free(codes); return 0; }
     if (!id) { id = (char *)xrealloc(NULL, 1); id[0] = 0; }
-    out->id = id; out->codes = codes; out->len = (int32_t)n;
+    out->id = id; out->codes = codes; out->len = (int32_t)n; out->after[0] = out->after[1] = 0;
     return 1;
 }
 

@@ -20,6 +20,7 @@ static void usage(void)
     fprintf(stderr, "-c: Print the computation time of each step.\n");
     fprintf(stderr, "-m ratio: Give a minimum match ratio ranging from 0 to 1.\n");
     fprintf(stderr, "-p: Use Pearson's correlation coefficient distance in place of Manhattan distance.\n");
+    fprintf(stderr, "-d n: (this build) use GPU n.  -B: (this build) results of a read depend on the longer reads before it in the file, as in reference mTR.\n");
 }
 
 /* ---- double-buffered ingest: a reader thread fills batches, main() consumes them in order ------------------------- */
@@ -129,6 +130,7 @@ static void finish_batch(run_t *run, mtr_ctx *ctx, batch_t *b)
             if (counts[i] > 0) { nchain[i] = mtrh_chain(recs + p, counts[i], chains + p); ntask += nchain[i]; }
             p += counts[i];
         }
+        for (int i = 0; i < n; i++) (void)mtr_get_bases_after_read(ctx, i, reads[i].after);     /* zeros unless -B */
         int32_t *t_read = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ntask > 0 ? ntask : 1));
         mtr_record *t_rec = (mtr_record *)malloc(sizeof(mtr_record) * (size_t)(ntask > 0 ? ntask : 1));
         if (!chains || !nchain || !cfirst || !t_read || !t_rec) { fprintf(stderr, "cannot allocate the alignment tasks\n"); exit(EXIT_FAILURE); }
@@ -156,10 +158,10 @@ static double now(void) { struct timeval t; gettimeofday(&t, NULL); return t.tv_
 
 int main(int argc, char **argv)
 {
-    int print_time = 0, print_alignment = 0, manhattan = 1, device = 0;
+    int print_time = 0, print_alignment = 0, manhattan = 1, device = 0, file_order = 0;
     float min_match_ratio = 0.6f;                 /* MIN_MATCH_RATIO, mTR.h:32 */
     int opt;
-    while ((opt = getopt(argc, argv, "acm:pd:")) != -1) {
+    while ((opt = getopt(argc, argv, "acm:pd:B")) != -1) {
         switch (opt) {
         case 'a': print_alignment = 1; break;
         case 'c': print_time = 1; break;
@@ -169,6 +171,7 @@ int main(int argc, char **argv)
             break;
         case 'p': manhattan = 0; fprintf(stderr, "Pearson's correlation coefficient distance in place of Manhattan distance.\n"); break;
         case 'd': device = atoi(optarg); break;    /* extension: GPU ordinal */
+        case 'B': file_order = 1; break;           /* extension: the reference's whole-file behaviour (mtr_hip.h, file-order mode) */
         default: usage(); exit(EXIT_FAILURE);
         }
     }
@@ -182,6 +185,8 @@ int main(int argc, char **argv)
     for (int k = 0; k < 2 && st == MTR_OK; k++) st = mtr_create(device, manhattan, min_match_ratio, &ctxs[k]);
     if (st != MTR_OK) { fprintf(stderr, "fatal error: no usable HIP device (mtr_create returned %d); this build has no CPU path\n", (int)st); exit(EXIT_FAILURE); }
 
+    mtr_file_state *fstate = NULL;                /* -B: what the reads of the file leave behind for the reads after them */
+    if (file_order && mtr_file_state_create(&fstate) != MTR_OK) { fprintf(stderr, "fatal error: out of memory\n"); exit(EXIT_FAILURE); }
     mtrh_fasta *fa = mtrh_fasta_open(argv[optind]);
     ingest_t ing;
     ingest_start(&ing, fa);
@@ -197,7 +202,8 @@ int main(int argc, char **argv)
         if (b->n == 0) { ingest_release(&ing, b); break; }
         mtr_ctx *ctx = ctxs[k & 1];
         t_mark = now();
-        st = mtr_upload_batch(ctx, b->bases, b->offs, b->lens, b->n);
+        st = fstate ? mtr_upload_batch_in_file(ctx, fstate, b->bases, b->offs, b->lens, b->n)     /* uploads happen in file order */
+                    : mtr_upload_batch(ctx, b->bases, b->offs, b->lens, b->n);
         if (st == MTR_OK) st = mtr_run_resident_async(ctx);
         if (st != MTR_OK) {                       /* like the reference: everything before the failing batch is reported first */
             if (prev) finish_batch(&run, prev_ctx, prev);
@@ -214,6 +220,7 @@ int main(int argc, char **argv)
                              run.t_wait, run.t_submit, run.t_fetch, run.t_kernel, run.t_chain);
     mtrh_fasta_close(fa);
     mtr_destroy(ctxs[0]); mtr_destroy(ctxs[1]);
+    mtr_file_state_destroy(fstate);
     if (print_time) {                             /* the reference's -c block (main.c:108-121) */
         fprintf(stderr, "Computation time\n");
         fprintf(stderr, "%f\tall\n", now() - t_all);

@@ -15,6 +15,8 @@ typedef struct {
     char    *id;                      /* header line after '>' */
     uint8_t *codes;                   /* 0..3 */
     int32_t  len;
+    uint8_t  after[2];                /* orgInputString[len], [len+1]: 0 = 'A' (isolated semantics); with -B the bases an
+                                       * earlier, longer read left there (mtr_get_bases_after_read) */
 } mtrh_read;
 
 /* Streaming FASTA reader with the reference's rules (handle_one_file.c:169-269): 4096-byte fgets chunks,

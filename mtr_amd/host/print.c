@@ -28,7 +28,7 @@ static void print_alignment(FILE *fp, const mtrh_read *rd, const mtr_record *r)
     int best = 0, bi = 0, bj = 0;
     for (int i = 1; i <= rows; i++) {
         const int p = base + i;
-        const int x = (p >= 0 && p < rd->len) ? rd->codes[p] : 0;        /* one past the read reads 'A' (isolated semantics) */
+        const int x = (p >= 0 && p < rd->len) ? rd->codes[p] : ((p >= rd->len && p < rd->len + 2) ? rd->after[p - rd->len] : 0);   /* one past the read: 'A' under isolated semantics */
         uint8_t *t = tb + (size_t)(i - 1) * (size_t)U;
         for (int j = 1; j <= U; j++) {
             int v, c;
@@ -59,7 +59,7 @@ static void print_alignment(FILE *fp, const mtrh_read *rd, const mtr_record *r)
         if (c == T_STOP) break;
         if (ncol + 1 >= cap) { cap *= 2; a_in = (char *)realloc(a_in, cap); a_sym = (char *)realloc(a_sym, cap); a_rep = (char *)realloc(a_rep, cap); }
         const int p = base + i;
-        const char xb = BASE[(p >= 0 && p < rd->len) ? rd->codes[p] : 0];
+        const char xb = BASE[(p >= 0 && p < rd->len) ? rd->codes[p] : ((p >= rd->len && p < rd->len + 2) ? rd->after[p - rd->len] : 0)];
         if (c == T_MATCH) { a_in[ncol] = xb; a_sym[ncol] = '|'; a_rep[ncol] = BASE[unit[j]]; i--; j--; }
         else if (c == T_MISMATCH) { a_in[ncol] = xb; a_sym[ncol] = ' '; a_rep[ncol] = BASE[unit[j]]; i--; j--; }
         else if (c == T_DEL) { a_in[ncol] = '-'; a_sym[ncol] = ' '; a_rep[ncol] = BASE[unit[j]]; j--; }
@@ -92,7 +92,7 @@ static void print_alignment_ops(FILE *fp, const mtrh_read *rd, const mtr_record 
     int p = end_pos, j = end_col;
     for (int64_t q = 0; q < n_ops; q++) {
         const int c = ops[q];
-        const char xb = BASE[(p >= 0 && p < rd->len) ? rd->codes[p] : 0];
+        const char xb = BASE[(p >= 0 && p < rd->len) ? rd->codes[p] : ((p >= rd->len && p < rd->len + 2) ? rd->after[p - rd->len] : 0)];
         const char ub = r->unit[j - 1];
         if (c == T_MATCH) { a_in[q] = xb; a_sym[q] = '|'; a_rep[q] = ub; p--; j--; }
         else if (c == T_MISMATCH) { a_in[q] = xb; a_sym[q] = ' '; a_rep[q] = ub; p--; j--; }

@@ -944,11 +944,26 @@ static void print_alignment(mtro_ctx *c, FILE *fp, const mtro_record *r)
     }
 }
 
+static void print_chain_with(mtro_ctx *c, FILE *fp, const char *read_id, int L, const mtro_record *recs,
+                             const int *chain_idx, int n_chain, int print_align);
 void mtro_print_chain(FILE *fp, const char *read_id, int L, const uint8_t *codes, const mtro_record *recs,
                       const int *chain_idx, int n_chain, int print_align)
 {
     mtro_ctx *c = NULL;
     if (print_align) { c = mtro_create(1, 0.6f); load_read(c, codes, L); }
+    print_chain_with(c, fp, read_id, L, recs, chain_idx, n_chain, print_align);
+    if (c) mtro_destroy(c);
+}
+/* the same for the read the context processed LAST, on the context's own orgInputString: in file-order mode a repeat
+ * can end on org[L], a base of an earlier read, and the reference prints that alignment from its global array */
+void mtro_print_chain_of_last_read(mtro_ctx *c, FILE *fp, const char *read_id, const mtro_record *recs,
+                                   const int *chain_idx, int n_chain, int print_align)
+{
+    print_chain_with(c, fp, read_id, c->L, recs, chain_idx, n_chain, print_align);
+}
+static void print_chain_with(mtro_ctx *c, FILE *fp, const char *read_id, int L, const mtro_record *recs,
+                             const int *chain_idx, int n_chain, int print_align)
+{
     for (int t = 0; t < n_chain; t++) {
         const mtro_record *r = &recs[chain_idx[t]];
         fprintf(fp, "%s\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%f\t%d\t%d\t%d\t%s\n", read_id, L, r->rep_start + 1, r->rep_end + 1,
@@ -956,7 +971,6 @@ void mtro_print_chain(FILE *fp, const char *read_id, int L, const uint8_t *codes
                 r->num_mismatches, r->num_insertions, r->num_deletions, r->unit);
         if (print_align) { fputc('\n', fp); print_alignment(c, fp, r); }
     }
-    if (c) mtro_destroy(c);
 }
 
 /* ================================================================================================

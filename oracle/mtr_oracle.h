@@ -68,6 +68,11 @@ int mtro_chain(const mtro_record *recs, int n, int *chain_idx);
 void mtro_print_chain(FILE *fp, const char *read_id, int L, const uint8_t *codes, const mtro_record *recs,
                       const int *chain_idx, int n_chain, int print_alignment);
 
+/* the same for the read the context processed last, printed from the context's own read buffer (file-order mode: a
+ * repeat can end on org[L], a base an earlier read left there) */
+void mtro_print_chain_of_last_read(mtro_ctx *, FILE *fp, const char *read_id, const mtro_record *recs,
+                                   const int *chain_idx, int n_chain, int print_alignment);
+
 /* stand-alone pieces, exported so that tests can drive the HIP kernels' building blocks */
 typedef struct {
     int32_t rep_start, rep_end, repeat_len, num_freq_unit, num_matches, num_mismatches, num_insertions, num_deletions;

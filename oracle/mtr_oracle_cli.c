@@ -48,7 +48,8 @@ int main(int argc, char **argv)
         if (nr > 0) {
             int *chain = (int *)malloc(sizeof(int) * (size_t)nr);
             int nc = mtro_chain(recs, nr, chain);
-            mtro_print_chain(stdout, ids[i], lens[i], seqs[i], recs, chain, nc, print_alignment);
+            if (file_order) mtro_print_chain_of_last_read(c, stdout, ids[i], recs, chain, nc, print_alignment);
+            else mtro_print_chain(stdout, ids[i], lens[i], seqs[i], recs, chain, nc, print_alignment);
             fflush(stdout);
             free(chain);
         }

@@ -50,6 +50,8 @@ def load(build: bool = True):
     lib.mtro_create.argtypes = [C.c_int, C.c_float]
     lib.mtro_create.restype = C.c_void_p
     lib.mtro_destroy.argtypes = [C.c_void_p]
+    lib.mtro_set_file_order.argtypes = [C.c_void_p, C.c_int]
+    lib.mtro_set_file_order.restype = None
     lib.mtro_process_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.POINTER(ORecord))]
     lib.mtro_process_read.restype = C.c_int
     lib.mtro_get_stats.argtypes = [C.c_void_p]
@@ -70,6 +72,10 @@ class Oracle:
     def __init__(self, manhattan: bool = True, min_match_ratio: float = 0.6):
         self.lib = load()
         self.h = C.c_void_p(self.lib.mtro_create(1 if manhattan else 0, C.c_float(min_match_ratio)))
+
+    def set_file_order(self, on: bool = True):
+        """the reference's behaviour on a multi-read file: process() must then be called in file order"""
+        self.lib.mtro_set_file_order(self.h, 1 if on else 0)
 
     def close(self):
         if self.h:

@@ -47,3 +47,21 @@ def test_cli_timing_block_and_errors(cli, tmp_path):
     assert q.returncode != 0 and b"Invalid character: N" in q.stderr
     r = subprocess.run([cli, "-m", "1.5", gu.input_path("3_5")], capture_output=True)
     assert r.returncode != 0 and b"must range from 0 to 1" in r.stderr
+
+
+@pytest.mark.parametrize("flags", [[], ["-p"], ["-a"]])
+def test_cli_file_order_mode(cli, flags):
+    """-B = the reference's behaviour on a multi-read file (include/mtr_hip.h, file-order mode).  Checked against the
+    oracle's -B mode, which is pinned to the reference run on whole files at every capture point and, like this driver,
+    breaks chaining ties by insertion order (the reference: by heap address)."""
+    from tests.oracle_binding import ORACLE_DIR
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "oracle"], check=True)
+    for name in ("mixed_lengths", "stale_org_base"):
+        fa = os.path.join(gu.GOLDEN, "file_order", name + ".fa")
+        want = subprocess.run([os.path.join(ORACLE_DIR, "mtr_oracle_cli"), "-B", *flags, fa], capture_output=True, check=True).stdout
+        p = subprocess.run([cli, "-B", *flags, fa], capture_output=True)
+        assert p.returncode == 0, p.stderr.decode()[:500]
+        assert p.stdout == want, name
+        if not flags:                                              # the isolated answers differ on these files
+            iso = subprocess.run([cli, fa], capture_output=True)
+            assert iso.returncode == 0 and iso.stdout != want

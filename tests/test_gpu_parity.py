@@ -10,6 +10,8 @@ Three kinds of evidence:
      independence (a read's records do not depend on which reads share its batch, nor on their order),
      run-to-run determinism, and a random sample against the oracle.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -316,3 +318,92 @@ def test_config4_mixed_lengths_every_read(eng):
         want = [w for ch in pool.map(_oracle_chunk, chunks) for w in ch]
     bad = [i for i in range(len(reads)) if [tuple(r) for r in got[i]] != want[i]]
     assert not bad, f"{len(bad)} of {len(reads)} reads differ, first: " + _diff_msg(bad[0], want[bad[0]], [tuple(r) for r in got[bad[0]]])
+
+
+# ---- file-order mode: the reference's behaviour on a multi-read file ---------------------------------------------------
+def _file_order_case():
+    """widely mixed lengths + reads ending inside their repeat right after a longer read (the one-past DP row)"""
+    reads = [c for _, c in synth.make_mixed_file(150, 21)]
+    rng = np.random.RandomState(5)
+    for n in (3000, 9, 1200, 31, 4, 700):
+        reads.append(rng.randint(0, 4, size=n).astype(np.uint8))
+        reads.append(np.concatenate([rng.randint(0, 4, size=max(0, n // 3)).astype(np.uint8), np.tile(rng.randint(0, 4, size=7).astype(np.uint8), 40)]))
+    return reads
+
+
+@pytest.mark.parametrize("manhattan,split", [(True, "0"), (True, "1"), (False, "0"), (False, "1")])
+def test_file_order_mode_matches_reference_behaviour_on_a_file(monkeypatch, manhattan, split):
+    """mtr_upload_batch_in_file: the records equal the oracle's file-order mode (pinned to the reference run on whole
+    files, tests/test_oracle_golden.py) whatever the batch boundaries, in both kernel modes; and they differ from the
+    isolated records on this input, so the test can fail."""
+    from tests.oracle_binding import Oracle
+    monkeypatch.setenv("MTR_SPLIT", split)
+    reads = _file_order_case()
+    o = Oracle(manhattan)
+    o.set_file_order(True)
+    want = [o.process(c) for c in reads]
+    o.close()
+    e = mtr_amd.Engine(manhattan=manhattan)
+    fs = mtr_amd.FileState()
+    got = []
+    for lo, hi in ((0, 1), (1, 8), (8, 97), (97, len(reads))):
+        got += e.process_in_file(reads[lo:hi], fs)
+    for i in range(len(reads)):
+        assert [tuple(r) for r in got[i]] == want[i], _diff_msg(i, want[i], [tuple(r) for r in got[i]])
+    iso = e.process(reads)
+    assert sum(1 for i in range(len(reads)) if [tuple(r) for r in iso[i]] != want[i]) >= 3
+    # a shard that starts in the middle of the file: the state of the reads before it comes from mtr_file_state_skip
+    fs2 = mtr_amd.FileState()
+    fs2.skip(reads[:60])
+    part = e.process_in_file(reads[60:110], fs2)
+    for i in range(60, 110):
+        assert [tuple(r) for r in part[i - 60]] == want[i], _diff_msg(i, want[i], [tuple(r) for r in part[i - 60]])
+    fs.close(); fs2.close(); e.close()
+
+
+def test_file_order_ranges_match_oracle():
+    """K1 alone in file-order mode against the oracle's DI ranges (bit patterns of the DI values included)"""
+    from tests.oracle_binding import Oracle
+    reads = _file_order_case()[:80]
+    for manhattan in (True, False):
+        o = Oracle(manhattan)
+        o.set_file_order(True)
+        e = mtr_amd.Engine(manhattan=manhattan)
+        fs = mtr_amd.FileState()
+        e.upload(reads, fs)
+        got = e.test_ranges()
+        for i, c in enumerate(reads):
+            want = o.ranges(c)
+            assert got[i] == want, f"read {i} (L={len(c)}): {len(want)} ranges expected, {len(got[i])} produced"
+        fs.close(); e.close(); o.close()
+
+
+@pytest.mark.parametrize("name", ["mixed_lengths", "stale_org_base"])
+@pytest.mark.parametrize("mode", ["default", "p"])
+def test_file_order_mode_golden(eng, eng_p, name, mode):
+    """against the capture of the unmodified reference run on the whole file (tests/golden/file_order/): candidate ranges
+    (G1, DI bit patterns included) and inserted records (G4) of every read.  stale_org_base.fa holds reads whose last
+    DP row reads orgInputString[L], i.e. a base of the previous longer read."""
+    import gzip, json
+    fo = os.path.join(gu.GOLDEN, "file_order")
+    reads = [c for _, c in gu.read_fasta(os.path.join(fo, name + ".fa"))]
+    per_read = []
+    with gzip.open(os.path.join(fo, f"{name}.{mode}.cap.jsonl.gz"), "rt") as fh:
+        for line in fh:
+            ev = json.loads(line)
+            if ev["t"] == "G1":
+                per_read.append({"G1": ev, "G4": []})
+            elif ev["t"] == "G4":
+                per_read[-1]["G4"].append(ev)
+    assert len(per_read) == len(reads)
+    e = eng if mode == "default" else eng_p
+    fs = mtr_amd.FileState()
+    e.upload(reads, fs)
+    ranges = e.test_ranges()
+    e.run()
+    got = e.fetch()
+    fs.close()
+    for i in range(len(reads)):
+        assert ranges[i] == gu.g1_usable(per_read[i]["G1"]), f"read {i}: ranges differ"
+        want = [gu.g4_tuple(ev) for ev in per_read[i]["G4"]]
+        assert [tuple(r) for r in got[i]] == want, _diff_msg(i, want, [tuple(r) for r in got[i]])

@@ -15,6 +15,7 @@ reference binary oracle/_ref/mTR_ref (CPU, slow) is scored on the same files nex
 from __future__ import annotations
 
 import argparse
+import collections
 import ctypes as C
 import os
 import subprocess
@@ -67,6 +68,8 @@ def main():
     ap.add_argument("--copies", type=int, default=10)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--reference", action="store_true", help="also score oracle/_ref/mTR_ref on the same reads (CPU)")
+    ap.add_argument("--file-order", action="store_true", help="run the GPU driver with -B (the reference's whole-file behaviour), so that "
+                    "with --reference the two reports can only differ where two chains tie")
     a = ap.parse_args()
     from mtr_amd import synth
 
@@ -86,13 +89,17 @@ def main():
             fa = os.path.join(td, f"u{u}.fa")
             synth.write_fasta(fa, reads)
             row = {"unit_len": u, "copies": a.copies, "reads": a.n}
+            outs = {}
             for label, exe in (("gpu", mtr),) + ((("ref", ref),) if a.reference else ()):
                 t0 = time.perf_counter()
-                p = subprocess.run([exe, fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                p = subprocess.run([exe] + (["-B"] if label == "gpu" and a.file_order else []) + [fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
                 if p.returncode != 0:
                     sys.exit(f"{exe} failed: {p.stderr[-400:]}")
                 row[label] = score(lib, p.stdout, truth)
                 row[label]["seconds"] = round(time.perf_counter() - t0, 2)
+                outs[label] = collections.Counter(p.stdout.split("\n"))
+            if len(outs) == 2:
+                row["report_lines_only_in_one"] = sum(((outs["gpu"] - outs["ref"]) + (outs["ref"] - outs["gpu"])).values())
             rows.append(row)
             print(row, flush=True)
     print()

@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--reads", type=int, default=READS_PER_GPU, help="reads per GPU (default = the headline workload)")
     ap.add_argument("--cpu-sample", type=int, default=2000, help="reads timed on the CPU baseline (0 = skip); 2000 reads ~ 15 s on one core")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--rehearse-exchange", action="store_true", help="development aid, 1 GPU: run the per-step record export of the "
+                    "multi-GPU path (compaction kernel + a device copy in place of the RCCL gather) to see what it costs the pipeline")
     a = ap.parse_args()
 
     import torch
@@ -117,14 +119,17 @@ def main():
     def finish(s):
         e = engs[s % 2]
         e.wait()
-        if world > 1:
+        if world > 1 or a.rehearse_exchange:
             # exchange step: gather the per-read record tables to rank 0 over RCCL
             total = e.counters()["records"]
             rb = rec_buf[s % 2]
             if rb is None or rb.numel() < total * RECORD_BYTES:
                 rb = rec_buf[s % 2] = torch.empty(max(total, 1) * RECORD_BYTES * 5 // 4, dtype=torch.uint8, device="cuda")
             counts, tot = e.export_records_device(rb.data_ptr(), rb.numel() // RECORD_BYTES)
-            gather_records(rb[: tot * RECORD_BYTES], torch.from_numpy(counts).cuda(), dst=0)
+            if world > 1:
+                gather_records(rb[: tot * RECORD_BYTES], torch.from_numpy(counts).cuda(), dst=0)
+            else:
+                rb[: tot * RECORD_BYTES].clone(); torch.from_numpy(counts).cuda(); torch.cuda.current_stream().synchronize()
         return e.kernel_times_ms()
 
     def sync():

@@ -244,6 +244,24 @@ def test_very_long_read_with_several_repeats(eng, oracle):
     assert len(want) >= 3
 
 
+def test_read_of_the_maximum_length(eng, oracle):
+    """833 333 bases = the longest read whose padded buffer (L + 2r) still fits the reference's MAX_INPUT_LENGTH
+    (mTR.h:31): 20 passes over 10^6 positions, 95 000 candidate ranges, 620 records; one more base is refused."""
+    rng = np.random.RandomState(99)
+    parts = []
+    for unit_len, copies in ((180, 40), (3, 300), (60, 150)):
+        parts.append(rng.randint(0, 4, size=270000).astype(np.uint8))
+        parts.append(synth.make_read(rng, unit_len, copies, 0, 0)[0])
+    read = np.concatenate(parts)
+    read = np.concatenate([read, rng.randint(0, 4, size=833333 - len(read)).astype(np.uint8)])
+    got = eng.process([read])
+    want = oracle.process(read)
+    assert [tuple(r) for r in got[0]] == want, _diff_msg(0, want, [tuple(r) for r in got[0]])
+    assert len(want) > 500
+    with pytest.raises(mtr_amd.MtrError):
+        eng.process([np.zeros(833334, np.uint8)])
+
+
 # ---- range-parallel mode (small batches): same records as one wavefront per read -----------------------------------
 @pytest.mark.parametrize("split", ["0", "1"])
 def test_range_parallel_mode_matches(monkeypatch, oracle, split):

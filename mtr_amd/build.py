@@ -13,7 +13,11 @@ SOURCES = ["mtr_abi.hip", "mtr_common.h", "device_util.hip.inc", "k1_ranges.hip.
            "dp_wrap.hip.inc", "min_missing_table.h", os.path.join("..", "..", "include", "mtr_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=off", "-fno-fast-math",      # fp64 DI values and float ratios must round exactly like the reference's C
-         "-fhip-fp32-correctly-rounded-divide-sqrt"]
+         "-fhip-fp32-correctly-rounded-divide-sqrt",
+         # The per-read kernel is one 9 000-line function at 128 VGPRs: hoisting loop invariants (mostly "pointer + lane"
+         # addresses) to its top made 275 of them spill and be reloaded inside the loops (19 GB of HBM traffic per launch,
+         # DESIGN.md 4.5).  No machine-level hoisting + sinking of what the IR level hoisted: 61 spilled VGPRs, +4.7 % reads/s.
+         "-mllvm", "-sink-insts-to-avoid-spills", "-mllvm", "-disable-machine-licm"]
 
 
 def hipcc() -> str:

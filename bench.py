@@ -109,22 +109,23 @@ def main():
     # alternate between them, so the kernels of step s+1 are enqueued while the last wavefronts of step s are
     # still finishing (a read is one wavefront's serial chain, the slowest read of a batch takes ~3x the mean).
     # Every step still does all of its work; only the barrier between steps is gone, as in a real multi-batch run.
-    engs = [mtr_amd.Engine(device=local_rank), mtr_amd.Engine(device=local_rank)]
+    NCTX = int(os.environ.get("MTR_BENCH_CONTEXTS", "2"))      # development knob: batches in flight
+    engs = [mtr_amd.Engine(device=local_rank) for _ in range(NCTX)]
     for e in engs:
         e.upload(reads)                                 # inputs resident in HBM before the timed region
     eng = engs[0]
 
-    rec_buf = [None, None]
+    rec_buf = [None] * NCTX
 
     def finish(s):
-        e = engs[s % 2]
+        e = engs[s % NCTX]
         e.wait()
         if world > 1 or a.rehearse_exchange:
             # exchange step: gather the per-read record tables to rank 0 over RCCL
             total = e.counters()["records"]
-            rb = rec_buf[s % 2]
+            rb = rec_buf[s % NCTX]
             if rb is None or rb.numel() < total * RECORD_BYTES:
-                rb = rec_buf[s % 2] = torch.empty(max(total, 1) * RECORD_BYTES * 5 // 4, dtype=torch.uint8, device="cuda")
+                rb = rec_buf[s % NCTX] = torch.empty(max(total, 1) * RECORD_BYTES * 5 // 4, dtype=torch.uint8, device="cuda")
             counts, tot = e.export_records_device(rb.data_ptr(), rb.numel() // RECORD_BYTES)
             if world > 1:
                 gather_records(rb[: tot * RECORD_BYTES], torch.from_numpy(counts).cuda(), dst=0)
@@ -139,19 +140,20 @@ def main():
 
     sync_k1, sync_k2 = [], []
     for w in range(a.warmup):                           # warm-up steps run one at a time (un-overlapped kernel times)
-        engs[w % 2].run_async()
+        engs[w % NCTX].run_async()
         kt = finish(w)
         sync_k1.append(kt["k1_ranges"]); sync_k2.append(kt["k2_units"])
     k2_ms, k1_ms = [], []
     sync()
     t0 = time.perf_counter()
-    engs[0].run_async()
-    for s in range(1, a.steps):
-        engs[s % 2].run_async()
-        kt = finish(s - 1)
+    depth = NCTX - 1                                    # steps enqueued ahead of the one being finished
+    for s in range(min(depth, a.steps)):
+        engs[s % NCTX].run_async()
+    for s in range(a.steps):
+        if s + depth < a.steps:
+            engs[(s + depth) % NCTX].run_async()
+        kt = finish(s)
         k1_ms.append(kt["k1_ranges"]); k2_ms.append(kt["k2_units"])
-    kt = finish(a.steps - 1)
-    k1_ms.append(kt["k1_ranges"]); k2_ms.append(kt["k2_units"])
     sync()
     dt = time.perf_counter() - t0
     if world > 1:

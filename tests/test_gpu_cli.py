@@ -65,3 +65,27 @@ def test_cli_file_order_mode(cli, flags):
         if not flags:                                              # the isolated answers differ on these files
             iso = subprocess.run([cli, fa], capture_output=True)
             assert iso.returncode == 0 and iso.stdout != want
+
+
+def test_reference_front_end_with_the_binding_of_integration_md():
+    """oracle/_ref/mTR_ref_gpu = the UNMODIFIED reference objects (main, reader, chaining, printers) with handle_one_file()
+    replaced by the binding of INTEGRATION.md (oracle/ref_gpu_binding.c), i.e. the drop-in the C-ABI is for.  Its stdout
+    is compared with the reference's own.  The reference's chaining breaks ties between equal chains by the heap
+    addresses of its Alignment objects (chaining.cpp:201), which differ between the two programs: where chains tie a
+    few lines differ (one of the three lines of 10_50 -p), so a case may miss at most max(2, 10 %) of the reference's lines and
+    most cases must be identical byte for byte."""
+    import collections
+    exe = os.path.join(ROOT, "oracle", "_ref", "mTR_ref_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/mTR_ref_gpu was not built (needs /root/reference at build time)")
+    cases = [(n, m) for n in ("3_5", "10_50", "2_5_10_20_set", "worm_chrI") for m in ("default", "p", "a")] + [("synth_c2", "default"), ("synth_c4", "default")]
+    exact = 0
+    for name, mode in cases:
+        p = subprocess.run([exe, *FLAGS[mode], gu.input_path(name)], capture_output=True)
+        assert p.returncode == 0, p.stderr.decode()[:500]
+        ref = open(os.path.join(gu.GOLDEN, f"{name}.{mode}.stdout"), "rb").read()
+        exact += p.stdout == ref
+        want, got = collections.Counter(ref.split(b"\n")), collections.Counter(p.stdout.split(b"\n"))
+        missing = sum((want - got).values())
+        assert missing <= max(2, 0.1 * sum(want.values())), (name, mode, missing)
+    assert exact >= len(cases) // 2, f"only {exact} of {len(cases)} identical"

@@ -104,15 +104,18 @@ static inline __host__ __device__ size_t k1_hist_bytes(int Lmax)
 }
 
 // ---- K2 per-wave scratch layout ------------------------------------------------------------------
-#define K2_NSLOT 4                 // unit slots: 0 = best of range, 1 = best of k, 2 = candidate, 3 = revision tmp
+#define K2_NSLOT_FIXED 4           // unit slots: 0 = best of range, 1 = best of k, 2 = candidate, 3 = revision tmp
+#define K2_POOL 24                 // + the candidate units of one range: <= 11 k x 2 walk directions (k2_range)
+#define K2_NSLOT (K2_NSLOT_FIXED + K2_POOL)
 #define K2_SLOT_UNIT 1024          // bytes of unit codes per slot (a revised unit can reach 2*499)
 #define K2_SLOT_SCORE 512          // int32 per slot
 #define K2_MEMO_N 32               // wrap_around_DP results remembered per candidate range (<= 11 k x 2 directions are made)
 #define K2_MEMO_UNIT 512           // bytes per remembered unit (MAX_PERIOD - 1 = 499 bases at most)
 struct K2Layout {
     size_t codes;                  // uint8 [cells]  traceback codes
-    size_t unit[K2_NSLOT];         // uint8 [1024]
-    size_t score[K2_NSLOT];        // int32 [512]
+    size_t unit0;                  // uint8 [K2_NSLOT][1024]
+    size_t score0;                 // int32 [K2_NSLOT][512]
+    size_t pool_meta, pool_res;    // int32 [K2_POOL][4] (period, k, direction), int32 [K2_POOL][16] (the DP result of the candidate)
     size_t cons, miss;             // int32 [501*5], [501*4]
     size_t pol_u, pol_rev;         // int32 [512] each (polish work arrays)
     size_t gkeys, gvals;           // int32 [gcap]: counts of the k-mer table (always) and keys of windows that do not fit LDS
@@ -137,8 +140,10 @@ static inline __host__ __device__ K2Layout k2_layout(int Lmax)
     y.gcap = g;
     size_t o = 0;
     y.codes = o; o = mtrc_align(o + y.cells, 256);
-    for (int i = 0; i < K2_NSLOT; i++) { y.unit[i] = o; o = mtrc_align(o + K2_SLOT_UNIT, 16); }
-    for (int i = 0; i < K2_NSLOT; i++) { y.score[i] = o; o = mtrc_align(o + K2_SLOT_SCORE * 4, 16); }
+    y.unit0 = o; o = mtrc_align(o + (size_t)K2_NSLOT * K2_SLOT_UNIT, 16);
+    y.score0 = o; o = mtrc_align(o + (size_t)K2_NSLOT * K2_SLOT_SCORE * 4, 16);
+    y.pool_meta = o; o = mtrc_align(o + (size_t)K2_POOL * 4 * 4, 16);
+    y.pool_res = o; o = mtrc_align(o + (size_t)K2_POOL * 16 * 4, 16);
     y.cons = o; o = mtrc_align(o + 501 * 5 * 4, 16);
     y.miss = o; o = mtrc_align(o + 501 * 4 * 4, 16);
     y.pol_u = o; o = mtrc_align(o + 512 * 4, 16);

@@ -111,6 +111,7 @@ static inline __host__ __device__ size_t k1_hist_bytes(int Lmax)
 #define K2_SLOT_SCORE 512          // int32 per slot
 #define K2_MEMO_N 32               // wrap_around_DP results remembered per candidate range (<= 11 k x 2 directions are made)
 #define K2_MEMO_UNIT 512           // bytes per remembered unit (MAX_PERIOD - 1 = 499 bases at most)
+#define K2_STEP_CACHE 32           // look-ahead decisions remembered per k-mer table and walk direction
 #define K2_RMEMO_N 16              // revision rounds remembered per candidate range (the k of a range often polish to the same unit)
 struct K2Layout {
     size_t codes;                  // uint8 [cells]  traceback codes
@@ -122,6 +123,7 @@ struct K2Layout {
     size_t gkeys, gvals;           // int32 [gcap]: counts of the k-mer table (always) and keys of windows that do not fit LDS
     size_t ties;                   // int32 [2][1024] tie lists of the look-ahead
     size_t memo_unit, memo_res;    // DP memo of the current range: uint8 [K2_MEMO_N][512] units, int32 [K2_MEMO_N][16] results
+    size_t step_cache;             // int32 [2][K2_STEP_CACHE][2]: node -> next node of the walks' general look-ahead steps, per direction
     size_t rmemo_key, rmemo_kunit, rmemo_val, rmemo_vunit;   // revision memo: int32 [N][16] + uint8 [N][512] in, int32 [N][16] + uint8 [N][1024] out
     size_t total;
     size_t cells; unsigned gcap;
@@ -153,6 +155,7 @@ static inline __host__ __device__ K2Layout k2_layout(int Lmax)
     y.ties = o; o = mtrc_align(o + 2 * MTRC_MAX_TIEBREAKS * 4, 16);
     y.memo_unit = o; o = mtrc_align(o + (size_t)K2_MEMO_N * K2_MEMO_UNIT, 16);
     y.memo_res = o; o = mtrc_align(o + (size_t)K2_MEMO_N * 16 * 4, 16);
+    y.step_cache = o; o = mtrc_align(o + (size_t)2 * K2_STEP_CACHE * 2 * 4, 16);
     y.rmemo_key = o; o = mtrc_align(o + (size_t)K2_RMEMO_N * 16 * 4, 16);
     y.rmemo_kunit = o; o = mtrc_align(o + (size_t)K2_RMEMO_N * K2_MEMO_UNIT, 16);
     y.rmemo_val = o; o = mtrc_align(o + (size_t)K2_RMEMO_N * 16 * 4, 16);

@@ -127,7 +127,10 @@ def main():
     # alternate between them, so the kernels of step s+1 are enqueued while the last wavefronts of step s are
     # still finishing (a read is one wavefront's serial chain, the slowest read of a batch takes ~3x the mean).
     # Every step still does all of its work; only the barrier between steps is gone, as in a real multi-batch run.
-    NCTX = int(os.environ.get("MTR_BENCH_CONTEXTS", "2"))      # development knob: batches in flight
+    # batches in flight: 2 on one GPU (3 and 4 measured: no gain).  With an exchange step (N > 1) one more, so that the next
+    # kernel is already enqueued while the host waits for the gather of the previous step, whose RCCL kernels may only get
+    # their wave slots when the resident kernel's first waves retire
+    NCTX = int(os.environ.get("MTR_BENCH_CONTEXTS", "2" if world == 1 else "3"))
     engs = [mtr_amd.Engine(device=local_rank) for _ in range(NCTX)]
     for e in engs:
         e.upload(reads)                                 # inputs resident in HBM before the timed region

@@ -35,16 +35,19 @@ extern "C" {
 #endif
 
 #define MTR_MAX_PERIOD 500          /* reference mTR.h:35 MAX_PERIOD */
-#define MTR_MAX_INPUT_LENGTH 1000000 /* reference mTR.h:31 */
-#define MTR_ABI_VERSION 1
+#define MTR_MAX_INPUT_LENGTH 1000000 /* reference mTR.h:31: the reader's limit (a read that reaches it is fatal) */
+/* Longest read the hot path takes: the reference's buffers hold L + 2r entries with r = L/10 random flank bases
+ * (handle_one_read.c:194-204), so beyond L + 2r = MAX_INPUT_LENGTH it writes out of bounds; uploads refuse such reads. */
+#define MTR_MAX_READ_LENGTH 833333
+#define MTR_ABI_VERSION 2
 
 typedef enum {
     MTR_OK = 0,
     MTR_ERR_NO_DEVICE = 1,      /* no HIP device / HIP runtime error at create */
-    MTR_ERR_BAD_ARG = 2,        /* null pointer, bad length (<=0 or > MTR_MAX_INPUT_LENGTH), bad code (>3) */
+    MTR_ERR_BAD_ARG = 2,        /* null pointer, bad length (<=0 or > MTR_MAX_READ_LENGTH), bad code (>3) */
     MTR_ERR_OOM = 3,            /* host or device allocation failed */
     MTR_ERR_HIP = 4,            /* a HIP call failed; mtr_last_error() has the text */
-    MTR_ERR_OVERFLOW = 5,       /* a per-read result buffer overflowed (raise MTR_MAX_RECORDS_PER_READ) */
+    MTR_ERR_OVERFLOW = 5,       /* a read produced more candidate ranges than L/2+64, or a caller-owned destination is too small */
     MTR_ERR_DP_TOO_LARGE = 6    /* a DP exceeded the reference's WrapDPsize (mTR.h:51): the reference exits */
 } mtr_status;
 
@@ -80,7 +83,7 @@ int        mtr_abi_version(void);
 /* Replaces the per-read loop body of handle_one_file.c:281-287 for n_reads reads at once.
  *   bases    concatenated base codes, one byte per base, 0..3 = A C G T (handle_one_file.c:169-188)
  *   offsets  n_reads start offsets into bases
- *   lens     n_reads lengths (1..MTR_MAX_INPUT_LENGTH)
+ *   lens     n_reads lengths (1..MTR_MAX_READ_LENGTH)
  * On success *out_records is a malloc'ed array of all records, read after read, each read's records
  * in insertion order; (*out_counts)[i] is the number of records of read i.  Free both with
  * mtr_free_results(). */
@@ -99,6 +102,63 @@ mtr_status mtr_run_resident(mtr_ctx *ctx);
 mtr_status mtr_run_resident_async(mtr_ctx *ctx);
 mtr_status mtr_wait(mtr_ctx *ctx);
 mtr_status mtr_fetch_results(mtr_ctx *ctx, mtr_record **out_records, int32_t **out_counts, int64_t *out_total);
+/* A failed run (mtr_wait returned an error) is remembered: fetch / export / alignments of that batch return the same
+ * status instead of partial records.  After MTR_ERR_DP_TOO_LARGE the reads BEFORE the failing one (input order) are
+ * still valid — the reference has printed them when it exits (wrap_around_DP.c:96-99) — and can be fetched with
+ * mtr_fetch_results_packed(); *out_first_failed is the index of the first read whose DP exceeded WrapDPsize, or -1. */
+mtr_status mtr_get_first_failed_read(const mtr_ctx *ctx, int32_t *out_first_failed);
+
+/* ---- the host's own packing --------------------------------------------------------------------------------------
+ * mtr_upload_batch packs the reads to the device layout on the calling thread.  A host that parses FASTA on several
+ * threads packs there instead and hands over the finished image:
+ *   read i occupies mtr_packed_words(lens[i]) = lens[i]/16 + 4 consecutive 32-bit words starting at word woff[i];
+ *   base p of the read sits in word p>>4 at bits 31-2(p&15) .. 30-2(p&15) (first base in the top bits); every other
+ *   bit of the read's words is 0 (org[L], org[L+1] read as 'A': isolated semantics).
+ * mtr_pack_read writes one read's words (inline: a host needs no library for it); MTR_ERR_BAD_ARG for a code > 3. */
+static inline int64_t mtr_packed_words(int32_t len) { return (int64_t)(len / 16) + 4; }
+static inline mtr_status mtr_pack_read(const uint8_t *codes, int32_t len, uint32_t *dst_words)
+{
+    if (!codes || !dst_words || len <= 0) return MTR_ERR_BAD_ARG;
+    const int32_t full = len >> 4;
+    uint32_t seen = 0;
+    for (int32_t q = 0; q < full; q++) {
+        const uint8_t *c = codes + ((int64_t)q << 4);
+        uint32_t v = 0, o = 0;
+        for (int t = 0; t < 16; t++) { v = (v << 2) | c[t]; o |= c[t]; }
+        dst_words[q] = v; seen |= o;
+    }
+    uint32_t v = 0;
+    for (int32_t p = full << 4; p < len; p++) { v |= (uint32_t)codes[p] << (30 - 2 * (p & 15)); seen |= codes[p]; }
+    dst_words[full] = v; dst_words[full + 1] = 0; dst_words[full + 2] = 0; dst_words[full + 3] = 0;
+    return seen > 3 ? MTR_ERR_BAD_ARG : MTR_OK;
+}
+mtr_status mtr_upload_batch_packed(mtr_ctx *ctx, const uint32_t *packed, int64_t n_words, const int64_t *woff,
+                                   const int32_t *lens, int32_t n_reads);
+
+/* ---- wire form of the record table -------------------------------------------------------------------------------
+ * A mtr_record is 2560 bytes because unit[] and unit_score[] are sized for MAX_PERIOD; a typical record uses 600.  The
+ * wire form keeps what insert_an_alignment_into_set receives and nothing else, record after record:
+ *   14 int32 (rep_start .. reserved, as in mtr_record) | rep_period unit bytes 'A','C','G','T', zero-padded to a
+ *   multiple of 4 | rep_period int32 unit scores.
+ * mtr_fetch_results_packed: the records of the last run in wire form, compacted on the device and copied into PINNED
+ * host memory owned by the context (valid until the next upload / fetch on this context; do not free).  Reads
+ * first_read .. first_read+n-1 only when n_reads_limit >= 0 (after MTR_ERR_DP_TOO_LARGE: the reads before the failing
+ * one); pass -1 for all.  mtr_export_packed_device: the same into caller-owned DEVICE memory (for RCCL).
+ * mtr_unpack_records / mtr_pack_records convert on the host (no device needed). */
+#define MTR_WIRE_HEADER_BYTES 56
+static inline int64_t mtr_wire_record_bytes(int32_t rep_period)
+{
+    const int64_t p = rep_period < 0 ? 0 : (rep_period > MTR_MAX_PERIOD ? MTR_MAX_PERIOD : rep_period);
+    return MTR_WIRE_HEADER_BYTES + ((p + 3) & ~(int64_t)3) + 4 * p;
+}
+mtr_status mtr_fetch_results_packed(mtr_ctx *ctx, int32_t n_reads_limit, const uint8_t **out_blob, int64_t *out_bytes,
+                                    const int32_t **out_counts, int64_t *out_total_records);
+mtr_status mtr_export_packed_device(mtr_ctx *ctx, void *d_dst, int64_t capacity_bytes, int32_t *counts_host,
+                                    int64_t *out_total_records, int64_t *out_bytes);
+/* out must hold n_records entries; only the fields a record carries are written (unit is NUL-terminated) */
+mtr_status mtr_unpack_records(const uint8_t *blob, int64_t bytes, int64_t n_records, mtr_record *out);
+/* returns the number of bytes written, or -1 if capacity is too small */
+int64_t    mtr_pack_records(const mtr_record *records, int64_t n_records, uint8_t *out, int64_t capacity);
 
 /* File-order mode = the reference's own behaviour on a multi-read file (leak A, and H2) instead of
  * isolated semantics.  The reference's inputString_w_rand and orgInputString live for the whole file
@@ -157,27 +217,6 @@ mtr_status mtr_get_kernel_times(const mtr_ctx *ctx, mtr_kernel_time *out, int32_
                              * [32] wrap_around_DP calls answered from the per-range memo (same window, same unit),
                              * [33] DP cells those calls would have filled, [34] k-mer tables proven unnecessary */
 mtr_status mtr_get_counters(const mtr_ctx *ctx, int64_t *out, int32_t n);
-
-/* ---- building blocks, exported for parity tests (same kernels the batch path runs) ------------- */
-
-/* K1 alone = fill_directional_index_with_end (fill_directional_index.c:549-602) for every read of the
- * uploaded batch.  Returns per read the surviving candidate ranges (start ascending): start, end, w
- * and the DI value's IEEE-754 bit pattern.  Arrays are malloc'ed; free() them. */
-mtr_status mtr_test_ranges(mtr_ctx *ctx, int32_t **out_counts, int32_t **out_start, int32_t **out_end,
-                           int32_t **out_w, uint64_t **out_di_bits, int64_t *out_total);
-
-/* wrap_around_DP_sub (wrap_around_DP.c:222-354) for n_tasks (read, window, unit, scores) tasks on the
- * uploaded batch.  unit codes 0..3, units concatenated, unit_off[n_tasks+1].  out8[8*t..] =
- * rep_start, rep_end, repeat_len, Num_freq_unit, matches, mismatches, insertions, deletions. */
-mtr_status mtr_test_wrap_dp(mtr_ctx *ctx, int32_t n_tasks, const int32_t *read_idx, const int32_t *query_start,
-                            const int32_t *query_end, const uint8_t *units, const int32_t *unit_off,
-                            const int32_t *gain, const int32_t *mismatch, const int32_t *indel, int32_t *out8);
-
-/* Event trace of the last run (debug aid for parity work): enable before mtr_run_resident.
- * Each event is 16 int32: [0]=type (2 search, 3 DP, 4 polish, 5 revise, 6 record), [1]=read index,
- * then type-specific fields (see mtr_amd/csrc/mtr_device.hip). */
-mtr_status mtr_set_trace(mtr_ctx *ctx, int32_t max_events);
-mtr_status mtr_get_trace(mtr_ctx *ctx, int32_t **out_events, int64_t *out_n);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,8 @@ EXPORTS = ["mtr_create", "mtr_destroy", "mtr_last_error", "mtr_abi_version", "mt
            "mtr_test_ranges", "mtr_test_wrap_dp", "mtr_set_trace", "mtr_get_trace", "mtr_export_records_device",
            "mtr_run_resident_async", "mtr_wait", "mtr_alignments",
            "mtr_file_state_create", "mtr_file_state_destroy", "mtr_upload_batch_in_file", "mtr_file_state_skip",
-           "mtr_get_bases_after_read"]
+           "mtr_get_bases_after_read", "mtr_upload_batch_packed", "mtr_fetch_results_packed", "mtr_export_packed_device",
+           "mtr_unpack_records", "mtr_pack_records", "mtr_get_first_failed_read"]
 
 
 class MtrError(RuntimeError):
@@ -151,6 +152,18 @@ def load_library(path: str = LIB_PATH):
     lib.mtr_test_wrap_dp.restype = C.c_int
     lib.mtr_export_records_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, P(C.c_int64)]
     lib.mtr_export_records_device.restype = C.c_int
+    lib.mtr_upload_batch_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.mtr_upload_batch_packed.restype = C.c_int
+    lib.mtr_fetch_results_packed.argtypes = [C.c_void_p, C.c_int32, P(C.c_void_p), P(C.c_int64), P(C.c_void_p), P(C.c_int64)]
+    lib.mtr_fetch_results_packed.restype = C.c_int
+    lib.mtr_export_packed_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, P(C.c_int64), P(C.c_int64)]
+    lib.mtr_export_packed_device.restype = C.c_int
+    lib.mtr_unpack_records.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    lib.mtr_unpack_records.restype = C.c_int
+    lib.mtr_pack_records.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+    lib.mtr_pack_records.restype = C.c_int64
+    lib.mtr_get_first_failed_read.argtypes = [C.c_void_p, P(C.c_int32)]
+    lib.mtr_get_first_failed_read.restype = C.c_int
     lib.mtr_set_trace.argtypes = [C.c_void_p, C.c_int32]
     lib.mtr_set_trace.restype = C.c_int
     lib.mtr_get_trace.argtypes = [C.c_void_p, P(P(C.c_int32)), P(C.c_int64)]
@@ -266,6 +279,55 @@ class Engine:
             out.append(lst)
         return out
 
+    def upload_packed(self, reads: Sequence[np.ndarray]):
+        """the host's own packing (mtr_upload_batch_packed): reads -> the 2-bit device image, packed here with numpy"""
+        lens = np.array([len(r) for r in reads], dtype=np.int32)
+        nw = lens.astype(np.int64) // 16 + 4
+        woff = np.zeros(len(reads), np.int64)
+        if len(reads) > 1:
+            woff[1:] = np.cumsum(nw[:-1])
+        packed = np.zeros(int(nw.sum()), np.uint32)
+        for i, r in enumerate(reads):
+            packed[woff[i]: woff[i] + nw[i]] = pack_read(np.asarray(r, np.uint8))
+        self._keep = (packed, woff, lens)
+        self._check(self.lib.mtr_upload_batch_packed(self.h, packed.ctypes.data, len(packed), woff.ctypes.data, lens.ctypes.data, len(reads)),
+                    "mtr_upload_batch_packed")
+        self.n_reads = len(reads)
+
+    def fetch_packed(self, limit: int = -1):
+        """mtr_fetch_results_packed: (wire blob bytes, counts int32[n]); the blob is copied out of the context's pinned staging"""
+        blob, cnts = C.c_void_p(), C.c_void_p()
+        nbytes, total = C.c_int64(), C.c_int64()
+        self._check(self.lib.mtr_fetch_results_packed(self.h, limit, C.byref(blob), C.byref(nbytes), C.byref(cnts), C.byref(total)), "mtr_fetch_results_packed")
+        n = self.n_reads if limit < 0 else min(limit, self.n_reads)
+        counts = np.ctypeslib.as_array(C.cast(cnts, C.POINTER(C.c_int32)), shape=(max(n, 1),))[:n].copy() if n > 0 and cnts.value else np.zeros(0, np.int32)
+        data = C.string_at(blob, nbytes.value) if nbytes.value else b""
+        return data, counts
+
+    def fetch_via_wire(self) -> List[List[Record]]:
+        """the records of the last run through the wire form and mtr_unpack_records (must equal fetch())"""
+        data, counts = self.fetch_packed()
+        total = int(counts.sum())
+        recs = (CRecord * max(total, 1))()
+        buf = C.create_string_buffer(data, len(data)) if data else C.create_string_buffer(1)
+        st = self.lib.mtr_unpack_records(buf, len(data), total, recs)
+        if st != 0:
+            raise MtrError(f"mtr_unpack_records: {STATUS.get(st, st)}")
+        return self._unpack(recs, counts, len(counts))
+
+    def export_packed_device(self, device_ptr: int, capacity_bytes: int):
+        """wire-form records into caller-owned device memory (for RCCL); returns (counts int32[n_reads], records, bytes)"""
+        counts = np.zeros(self.n_reads, np.int32)
+        total, nbytes = C.c_int64(), C.c_int64()
+        self._check(self.lib.mtr_export_packed_device(self.h, C.c_void_p(device_ptr), capacity_bytes, counts.ctypes.data, C.byref(total), C.byref(nbytes)),
+                    "mtr_export_packed_device")
+        return counts, int(total.value), int(nbytes.value)
+
+    def first_failed_read(self) -> int:
+        v = C.c_int32()
+        self.lib.mtr_get_first_failed_read(self.h, C.byref(v))
+        return int(v.value)
+
     def export_records_device(self, device_ptr: int, capacity_records: int):
         """Compacts the last run's records into caller-owned device memory; returns (counts int32[n_reads], total)."""
         counts = np.zeros(self.n_reads, np.int32)
@@ -326,6 +388,17 @@ class Engine:
         arr = np.ctypeslib.as_array(ev, shape=(max(n.value, 1), 16))[: n.value].copy()
         _libc.free(C.cast(ev, C.c_void_p))
         return arr
+
+
+def pack_read(codes: np.ndarray) -> np.ndarray:
+    """one read in the device layout of include/mtr_hip.h ("the host's own packing"): len//16 + 4 words, first base in the
+    top bits of word 0, zero behind the read"""
+    n = len(codes)
+    nw = n // 16 + 4
+    padded = np.zeros(nw * 16, np.uint32)
+    padded[:n] = codes
+    shifts = (30 - 2 * np.arange(16, dtype=np.uint32)).astype(np.uint32)
+    return np.bitwise_or.reduce(padded.reshape(nw, 16) << shifts, axis=1).astype(np.uint32)
 
 
 def codes_from_str(s: str) -> np.ndarray:

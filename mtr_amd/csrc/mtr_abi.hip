@@ -20,13 +20,17 @@
 #include <string>
 #include <vector>
 
+#include <mutex>
+
 #include "../../include/mtr_hip.h"
+#include "../../include/mtr_hip_test.h"
 #include "mtr_common.h"
 #include "k1_ranges.hip.inc"
 #include "k2_units.hip.inc"
 
 static_assert(sizeof(DevRecord) == sizeof(mtr_record), "device and ABI record layouts must agree");
 static_assert(MTR_N_COUNTERS == CNT_N, "counter count");
+static_assert(MTR_MAX_READ_LENGTH == MTRC_MAX_SUPPORTED_LENGTH, "read length limit");
 
 // ---- MT19937 (reference MT.h = stock mt19937ar), host-precomputed base stream -------------------------
 static void mt_bases(std::vector<uint8_t> &out, size_t n)
@@ -84,7 +88,27 @@ struct mtr_ctx {
     mtr_kernel_time kt[2] = { { 0, 0 }, { 0, 0 } };
     unsigned long long counters[CNT_N] = { 0 };
     bool ran = false, pending = false;
+    mtr_status run_status = MTR_OK;                    // of the last run: latched until the next upload
+    int32_t first_failed = -1; int32_t *d_fail_read = nullptr;   // first read (input order) whose DP exceeded WrapDPsize
+    // wire-form fetch: per-read byte sizes / offsets on the device, pinned staging on the host (grow-only)
+    int64_t *d_wire_bytes = nullptr, *d_wire_off = nullptr; uint8_t *d_wire = nullptr;
+    void *h_counts = nullptr, *h_sizes = nullptr, *h_blob = nullptr; size_t h_counts_cap = 0, h_sizes_cap = 0, h_blob_cap = 0;
+    // -a: task buffers of mtr_alignments (grow-only, like the batch buffers)
+    int32_t *d_al_i32 = nullptr, *d_al_len = nullptr, *d_al_ends = nullptr; uint8_t *d_al_units = nullptr, *d_al_ops = nullptr; int64_t *d_al_off = nullptr;
+    // test entry points
+    int32_t *d_t_i32 = nullptr, *d_t_out = nullptr; uint8_t *d_t_units = nullptr;
 };
+
+// The MT19937 base stream is the same for every read and every context: one device copy per GPU, shared by the
+// contexts on it (a second context costs no generation and no upload).
+static std::mutex g_mt_mu;
+static struct { uint8_t *d = nullptr; int refs = 0; } g_mt[64];
+static std::vector<uint8_t> g_mt_host;
+static const std::vector<uint8_t> &mt_host()
+{   // callers hold g_mt_mu
+    if (g_mt_host.empty()) mt_bases(g_mt_host, (size_t)MTRC_MAX_INPUT_LENGTH + 2 * 100000 + 64);
+    return g_mt_host;
+}
 
 // ---- file-order mode: the host shadow of the reference's process-wide buffers ---------------------------------------
 // The reference keeps inputString_w_rand and orgInputString for the whole file (handle_one_file.c:85, mTR.h:65-67).  A
@@ -151,7 +175,7 @@ extern "C" mtr_status mtr_file_state_create(mtr_file_state **out)
     if (!out) return MTR_ERR_BAD_ARG;
     mtr_file_state *fs = new (std::nothrow) mtr_file_state();
     if (!fs) { *out = nullptr; return MTR_ERR_OOM; }
-    mt_bases(fs->mt, (size_t)MTRC_MAX_INPUT_LENGTH + 2 * 100000 + 64);
+    { std::lock_guard<std::mutex> lk(g_mt_mu); fs->mt = mt_host(); }
     *out = fs;
     return MTR_OK;
 }
@@ -203,7 +227,7 @@ template <typename T> static hipError_t ensure_dev(mtr_ctx *ctx, T *&p, size_t b
 }
 
 // forget the resident batch (its buffers stay allocated for the next one)
-static void free_batch(mtr_ctx *ctx) { ctx->n_reads = 0; ctx->ran = false; }
+static void free_batch(mtr_ctx *ctx) { ctx->n_reads = 0; ctx->ran = false; ctx->run_status = MTR_OK; ctx->first_failed = -1; ctx->ovf_reads.clear(); }
 // release every batch buffer (mtr_destroy)
 static void release_batch_buffers(mtr_ctx *ctx)
 {
@@ -213,7 +237,24 @@ static void release_batch_buffers(mtr_ctx *ctx)
     dfree(ctx->d_ovf_records); dfree(ctx->d_rec_base); dfree(ctx->d_ovf_order); dfree(ctx->d_src);
     dfree(ctx->d_item_read); dfree(ctx->d_item_idx); dfree(ctx->d_cand_flag); dfree(ctx->d_item_off); dfree(ctx->d_cand); ctx->item_cap = 0;
     dfree(ctx->d_tail); dfree(ctx->d_tail_off);
+    dfree(ctx->d_wire_bytes); dfree(ctx->d_wire_off); dfree(ctx->d_wire);
+    dfree(ctx->d_al_i32); dfree(ctx->d_al_len); dfree(ctx->d_al_ends); dfree(ctx->d_al_units); dfree(ctx->d_al_ops); dfree(ctx->d_al_off);
+    dfree(ctx->d_t_i32); dfree(ctx->d_t_out); dfree(ctx->d_t_units);
     ctx->caps.clear();
+    if (ctx->h_counts) { (void)hipHostFree(ctx->h_counts); ctx->h_counts = nullptr; ctx->h_counts_cap = 0; }
+    if (ctx->h_sizes) { (void)hipHostFree(ctx->h_sizes); ctx->h_sizes = nullptr; ctx->h_sizes_cap = 0; }
+    if (ctx->h_blob) { (void)hipHostFree(ctx->h_blob); ctx->h_blob = nullptr; ctx->h_blob_cap = 0; }
+}
+
+// pinned host staging, grow-only
+static hipError_t ensure_pinned(void *&p, size_t &cap, size_t bytes)
+{
+    if (p && bytes <= cap) return hipSuccess;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
 }
 
 extern "C" int mtr_abi_version(void) { return MTR_ABI_VERSION; }
@@ -238,12 +279,18 @@ extern "C" mtr_status mtr_create(int device, int manhattan, float min_match_rati
     ok = ok && hipMalloc(&ctx->d_work, sizeof(unsigned)) == hipSuccess;
     ok = ok && hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * CNT_N) == hipSuccess;
     ok = ok && hipMalloc(&ctx->d_trace_n, sizeof(unsigned)) == hipSuccess;
-    if (ok) {
+    ok = ok && hipMalloc(&ctx->d_fail_read, sizeof(int32_t)) == hipSuccess;
+    if (ok && device < 64) {
         // the read-independent MT19937 base stream: first min(L+4r,1e6) draws + two flanks of r <= 1e5
-        std::vector<uint8_t> mt;
-        mt_bases(mt, (size_t)MTRC_MAX_INPUT_LENGTH + 2 * 100000 + 64);
-        ok = hipMalloc(&ctx->d_mt, mt.size()) == hipSuccess && copy_sync(ctx, ctx->d_mt, mt.data(), mt.size(), hipMemcpyHostToDevice) == hipSuccess;
-    }
+        std::lock_guard<std::mutex> lk(g_mt_mu);
+        if (!g_mt[device].d) {
+            const std::vector<uint8_t> &mt = mt_host();
+            uint8_t *d = nullptr;
+            ok = hipMalloc(&d, mt.size()) == hipSuccess && copy_sync(ctx, d, mt.data(), mt.size(), hipMemcpyHostToDevice) == hipSuccess;
+            if (ok) g_mt[device].d = d; else if (d) (void)hipFree(d);
+        }
+        if (ok) { ctx->d_mt = g_mt[device].d; g_mt[device].refs++; }
+    } else ok = false;
     if (!ok) { mtr_destroy(ctx); return MTR_ERR_NO_DEVICE; }
     *out = ctx;
     return MTR_OK;
@@ -254,8 +301,13 @@ extern "C" void mtr_destroy(mtr_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     release_batch_buffers(ctx);
-    dfree(ctx->d_mt); dfree(ctx->d_status); dfree(ctx->d_work); dfree(ctx->d_counters); dfree(ctx->d_scratch);
-    dfree(ctx->d_trace); dfree(ctx->d_trace_n);
+    if (ctx->d_mt) {
+        std::lock_guard<std::mutex> lk(g_mt_mu);
+        if (--g_mt[ctx->device].refs == 0) { (void)hipFree(g_mt[ctx->device].d); g_mt[ctx->device].d = nullptr; }
+        ctx->d_mt = nullptr;
+    }
+    dfree(ctx->d_status); dfree(ctx->d_work); dfree(ctx->d_counters); dfree(ctx->d_scratch);
+    dfree(ctx->d_trace); dfree(ctx->d_trace_n); dfree(ctx->d_fail_read);
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -293,38 +345,51 @@ static int pick_waves(mtr_ctx *ctx, int n_items, int per_cu, size_t per_wave, si
     return (int)waves;
 }
 
-static mtr_status upload_batch(mtr_ctx *ctx, mtr_file_state *fs, const uint8_t *bases, const int64_t *offsets, const int32_t *lens, int32_t n);
+static mtr_status upload_batch(mtr_ctx *ctx, mtr_file_state *fs, const uint32_t *packed_in, int64_t n_words_in, const int64_t *woff_in,
+                               const uint8_t *bases, const int64_t *offsets, const int32_t *lens, int32_t n);
 extern "C" mtr_status mtr_upload_batch(mtr_ctx *ctx, const uint8_t *bases, const int64_t *offsets, const int32_t *lens, int32_t n)
 {
-    return upload_batch(ctx, nullptr, bases, offsets, lens, n);
+    if (ctx && (!bases || !offsets)) { ctx->err = "null input"; return MTR_ERR_BAD_ARG; }
+    return upload_batch(ctx, nullptr, nullptr, 0, nullptr, bases, offsets, lens, n);
 }
 extern "C" mtr_status mtr_upload_batch_in_file(mtr_ctx *ctx, mtr_file_state *fs, const uint8_t *bases, const int64_t *offsets, const int32_t *lens, int32_t n)
 {
     if (!fs) { if (ctx) ctx->err = "null file state"; return MTR_ERR_BAD_ARG; }
-    return upload_batch(ctx, fs, bases, offsets, lens, n);
+    if (ctx && (!bases || !offsets)) { ctx->err = "null input"; return MTR_ERR_BAD_ARG; }
+    return upload_batch(ctx, fs, nullptr, 0, nullptr, bases, offsets, lens, n);
 }
-static mtr_status upload_batch(mtr_ctx *ctx, mtr_file_state *fs, const uint8_t *bases, const int64_t *offsets, const int32_t *lens, int32_t n)
+extern "C" mtr_status mtr_upload_batch_packed(mtr_ctx *ctx, const uint32_t *packed, int64_t n_words, const int64_t *woff, const int32_t *lens, int32_t n)
+{
+    if (ctx && (!packed || !woff || n_words <= 0)) { ctx->err = "null input"; return MTR_ERR_BAD_ARG; }
+    return upload_batch(ctx, nullptr, packed, n_words, woff, nullptr, nullptr, lens, n);
+}
+static mtr_status upload_batch(mtr_ctx *ctx, mtr_file_state *fs, const uint32_t *packed_in, int64_t n_words_in, const int64_t *woff_in,
+                               const uint8_t *bases, const int64_t *offsets, const int32_t *lens, int32_t n)
 {
     if (!ctx) return MTR_ERR_BAD_ARG;
-    if (!bases || !offsets || !lens || n <= 0) { ctx->err = "null input or n_reads <= 0"; return MTR_ERR_BAD_ARG; }
+    if (!lens || n <= 0) { ctx->err = "null input or n_reads <= 0"; return MTR_ERR_BAD_ARG; }
     HIPCHK(hipSetDevice(ctx->device));
     { mtr_status w = mtr_wait(ctx); if (w != MTR_OK && w != MTR_ERR_OVERFLOW && w != MTR_ERR_DP_TOO_LARGE) return w; }
     free_batch(ctx);
-    std::vector<int64_t> woff((size_t)n);
+    std::vector<int64_t> woff_own;
+    std::vector<uint32_t> packed_own;
+    const int64_t *woff = woff_in; const uint32_t *packed = packed_in;
     int64_t words = 0; int Lmax = 0;
     for (int i = 0; i < n; i++) {
         if (lens[i] <= 0 || lens[i] > MTRC_MAX_SUPPORTED_LENGTH) { ctx->err = "read " + std::to_string(i) + ": length " + std::to_string(lens[i]) + " outside 1.." + std::to_string(MTRC_MAX_SUPPORTED_LENGTH); return MTR_ERR_BAD_ARG; }
-        woff[(size_t)i] = words; words += lens[i] / 16 + 4;
         Lmax = std::max(Lmax, (int)lens[i]);
     }
-    words += 80;                                        // the DP stages 64-word blocks: keep the last block readable
-    std::vector<uint32_t> packed((size_t)words, 0u);
-    for (int i = 0; i < n; i++) {
-        const uint8_t *b = bases + offsets[i]; uint32_t *w = packed.data() + woff[(size_t)i];
-        for (int p = 0; p < lens[i]; p++) {
-            if (b[p] > 3) { ctx->err = "read " + std::to_string(i) + ": base code > 3"; return MTR_ERR_BAD_ARG; }
-            w[p >> 4] |= (uint32_t)b[p] << (30 - 2 * (p & 15));
-        }
+    if (packed_in) {
+        for (int i = 0; i < n; i++)
+            if (woff_in[i] < 0 || woff_in[i] + mtr_packed_words(lens[i]) > n_words_in) { ctx->err = "read " + std::to_string(i) + ": words outside the packed image"; return MTR_ERR_BAD_ARG; }
+        words = n_words_in;
+    } else {
+        woff_own.resize((size_t)n);
+        for (int i = 0; i < n; i++) { woff_own[(size_t)i] = words; words += mtr_packed_words(lens[i]); }
+        packed_own.assign((size_t)words, 0u);
+        for (int i = 0; i < n; i++)
+            if (mtr_pack_read(bases + offsets[i], lens[i], packed_own.data() + woff_own[(size_t)i]) != MTR_OK) { ctx->err = "read " + std::to_string(i) + ": base code > 3"; return MTR_ERR_BAD_ARG; }
+        woff = woff_own.data(); packed = packed_own.data();
     }
     // file-order mode: in file order, what each read finds beyond its own part of the reference's two buffers
     std::vector<uint16_t> tail; std::vector<int64_t> tail_off;
@@ -334,7 +399,7 @@ static mtr_status upload_batch(mtr_ctx *ctx, mtr_file_state *fs, const uint8_t *
         for (int i = 0; i < n; i++) {
             fs->tail_for(lens[i], tail);
             tail_off[(size_t)i + 1] = (int64_t)tail.size();
-            uint32_t *w = packed.data() + woff[(size_t)i];
+            uint32_t *w = packed_own.data() + woff_own[(size_t)i];
             for (int64_t p = lens[i]; p < (int64_t)lens[i] + 2; p++) {
                 const int b = fs->org_at(p);
                 ctx->after[(size_t)i * 2 + (size_t)(p - lens[i])] = (uint8_t)b;
@@ -352,7 +417,7 @@ static mtr_status upload_batch(mtr_ctx *ctx, mtr_file_state *fs, const uint8_t *
     ctx->lens.assign(lens, lens + n);
     ctx->n_reads = n; ctx->Lmax = Lmax;
     ctx->max_rec = 16 + Lmax / 100;
-    HIPCHK(ensure_dev(ctx, ctx->d_packed, packed.size() * 4));
+    HIPCHK(ensure_dev(ctx, ctx->d_packed, ((size_t)words + 80) * 4));      // + 80: the DP stages 64-word blocks, the last block must stay readable
     HIPCHK(ensure_dev(ctx, ctx->d_woff, (size_t)n * 8)); HIPCHK(ensure_dev(ctx, ctx->d_lens, (size_t)n * 4)); HIPCHK(ensure_dev(ctx, ctx->d_order, (size_t)n * 4));
     HIPCHK(ensure_dev(ctx, ctx->d_roff, ((size_t)n + 1) * 8)); HIPCHK(ensure_dev(ctx, ctx->d_rcount, (size_t)n * 4));
     HIPCHK(ensure_dev(ctx, ctx->d_rstart, (size_t)ctx->total_rcap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_rend, (size_t)ctx->total_rcap * 4));
@@ -361,8 +426,9 @@ static mtr_status upload_batch(mtr_ctx *ctx, mtr_file_state *fs, const uint8_t *
     HIPCHK(ensure_dev(ctx, ctx->d_reccount, (size_t)n * 4));
     HIPCHK(ensure_dev(ctx, ctx->d_recoff, ((size_t)n + 1) * 8));
     HIPCHK(ensure_dev(ctx, ctx->d_item_off, ((size_t)n + 1) * 8));
-    HIPCHK(hipMemcpyAsync(ctx->d_packed, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_woff, woff.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_packed, packed, (size_t)words * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_packed + words, 0, 80 * 4, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_woff, woff, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_lens, lens, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_roff, ctx->roff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -476,7 +542,7 @@ static void k2_args(mtr_ctx *ctx, K2Args &a, size_t per_wave)
     a.r_count = ctx->d_rcount; a.r_off = ctx->d_roff; a.r_start = ctx->d_rstart; a.r_end = ctx->d_rend; a.r_w = ctx->d_rw;
     a.records = ctx->d_records; a.max_rec_per_read = ctx->max_rec; a.rec_count = ctx->d_reccount; a.rec_base = nullptr;
     if (ctx->sub_active) { a.records = ctx->d_ovf_records; a.max_rec_per_read = ctx->ovf_cap; a.rec_base = ctx->d_rec_base; }
-    a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
+    a.status = ctx->d_status; a.fail_read = ctx->d_fail_read; a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
     a.trace = ctx->d_trace; a.trace_cap = ctx->trace_cap; a.trace_n = ctx->d_trace_n;
     a.trace_mask = getenv("MTR_TRACE_MASK") ? (int32_t)strtol(getenv("MTR_TRACE_MASK"), nullptr, 0) : -1;
     a.dp16_max_rows = dp16_max_rows();
@@ -548,7 +614,12 @@ static mtr_status launch_split(mtr_ctx *ctx)
     // few reads: one wavefront per (read, pass) in the range finder too (MTR_K1_PARTS_MAX_READS, default 256 reads:
     // [measured] 1 read 7.6 -> 6.5 ms, 100 reads of 42 kb 403 -> 348 ms, but 1024 reads of 2 kb 40 -> 45 ms)
     const long parts_max = getenv("MTR_K1_PARTS_MAX_READS") ? atol(getenv("MTR_K1_PARTS_MAX_READS")) : 256;
-    mtr_status s = (n <= parts_max) ? launch_k1_parts(ctx) : launch_k1(ctx); if (s != MTR_OK) return s;
+    bool parts = n <= parts_max;
+    if (parts) {   // the per-(read, pass) form keeps scratch per READ: only while that stays within the scratch budget
+        size_t tot = 0;
+        parts = pick_waves(ctx, n, n, k1_layout(ctx->Lmax).total, &tot) == n;
+    }
+    mtr_status s = parts ? launch_k1_parts(ctx) : launch_k1(ctx); if (s != MTR_OK) return s;
     std::vector<int32_t> rc((size_t)n);
     HIPCHK(copy_sync(ctx, rc.data(), ctx->d_rcount, (size_t)n * 4, hipMemcpyDeviceToHost));       // waits for the ranges kernel
     { mtr_status st = check_status(ctx); if (st != MTR_OK) return st; }
@@ -573,15 +644,7 @@ static mtr_status launch_split(mtr_ctx *ctx)
     size_t total = 0;
     const int waves = pick_waves(ctx, (int)std::max<int64_t>(items, 1), waves_per_cu(), y2.total, &total);
     s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;
-    K2Args a{};
-    a.b = view(ctx); a.min_match_ratio = ctx->min_ratio; a.Lmax = ctx->Lmax;
-    a.scratch = ctx->d_scratch; a.scratch_per_wave = y2.total;
-    a.r_count = ctx->d_rcount; a.r_off = ctx->d_roff; a.r_start = ctx->d_rstart; a.r_end = ctx->d_rend; a.r_w = ctx->d_rw;
-    a.records = ctx->d_records; a.max_rec_per_read = ctx->max_rec; a.rec_count = ctx->d_reccount; a.rec_base = nullptr;
-    a.status = ctx->d_status; a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
-    a.trace = ctx->d_trace; a.trace_cap = ctx->trace_cap; a.trace_n = ctx->d_trace_n;
-    a.trace_mask = getenv("MTR_TRACE_MASK") ? (int32_t)strtol(getenv("MTR_TRACE_MASK"), nullptr, 0) : -1;
-    a.dp16_max_rows = dp16_max_rows();
+    K2Args a{}; k2_args(ctx, a, y2.total);
     SplitArgs sp{};
     sp.item_read = ctx->d_item_read; sp.item_idx = ctx->d_item_idx; sp.item_off = ctx->d_item_off; sp.n_items = (int32_t)items;
     sp.cand = ctx->d_cand; sp.cand_flag = ctx->d_cand_flag;
@@ -630,8 +693,10 @@ extern "C" mtr_status mtr_run_resident_async(mtr_ctx *ctx)
     if (!ctx) return MTR_ERR_BAD_ARG;
     if (ctx->n_reads <= 0) { ctx->err = "no batch uploaded"; return MTR_ERR_BAD_ARG; }
     HIPCHK(hipSetDevice(ctx->device));
-    { mtr_status w = mtr_wait(ctx); if (w != MTR_OK) return w; }
+    { mtr_status w = mtr_wait(ctx); if (w != MTR_OK && ctx->pending) return w; }
+    ctx->run_status = MTR_OK; ctx->ran = false; ctx->first_failed = -1; ctx->ovf_reads.clear();
     HIPCHK(hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_fail_read, 0x7f, 4, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
     ctx->last_split = use_split(ctx);
     mtr_status s = ctx->last_split ? launch_split(ctx) : launch_reads(ctx); if (s != MTR_OK) return s;
@@ -642,17 +707,28 @@ extern "C" mtr_status mtr_run_resident_async(mtr_ctx *ctx)
 extern "C" mtr_status mtr_wait(mtr_ctx *ctx)
 {
     if (!ctx) return MTR_ERR_BAD_ARG;
-    if (!ctx->pending) return MTR_OK;
+    if (!ctx->pending) return ctx->run_status;
     HIPCHK(hipSetDevice(ctx->device));
+    ctx->pending = false; ctx->ran = false; ctx->run_status = MTR_ERR_HIP;   // until everything below succeeded
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->pending = false;
     float ms = 0;
     ctx->kt[0].ms = 0; ctx->kt[0].launches = 0;                // K1 runs inside the per-read kernel
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->kt[1].ms = ms; ctx->kt[1].launches = 1;
     HIPCHK(copy_sync(ctx, ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
-    ctx->ran = true;
-    { mtr_status st = check_status(ctx); if (st != MTR_OK) return st; }
-    return resolve_overflow(ctx);
+    mtr_status st = check_status(ctx);
+    if (st == MTR_ERR_DP_TOO_LARGE) {
+        int32_t fr = -1;
+        if (copy_sync(ctx, &fr, ctx->d_fail_read, 4, hipMemcpyDeviceToHost) == hipSuccess && fr >= 0 && fr < ctx->n_reads) ctx->first_failed = fr;
+    }
+    if (st == MTR_OK || st == MTR_ERR_DP_TOO_LARGE) {
+        // reads that found more records than their slots are run again (also after a DP failure: the reads before the
+        // failing one are still reported, as the reference has printed them when it exits)
+        const mtr_status so = resolve_overflow(ctx);
+        if (so != MTR_OK && so != MTR_ERR_DP_TOO_LARGE) st = so;
+    }
+    ctx->run_status = st;
+    ctx->ran = (st == MTR_OK);
+    return st;
 }
 
 extern "C" mtr_status mtr_run_resident(mtr_ctx *ctx)
@@ -679,45 +755,215 @@ static mtr_status record_sources(mtr_ctx *ctx, const DevRecord *const **out)
 __global__ void mtr_k_compact(const DevRecord *in, const DevRecord *const *src_of, const int32_t *cnt, const int64_t *off, int max_rec, int n_reads, DevRecord *out)
 {
     // one block per read; records are copied as 16-byte words.  src_of (optional) = where each read's records are
-    // (reads that were run again with more slots have theirs in the overflow buffer)
+    // (reads that were run again with more slots have theirs in the overflow buffer; every other read has at most max_rec)
     int rd = blockIdx.x;
     if (rd >= n_reads) return;
     int c = cnt[rd];
+    if (!src_of && c > max_rec) c = max_rec;
     const uint4 *src = (const uint4 *)(src_of ? src_of[rd] : in + (size_t)rd * (size_t)max_rec);
     uint4 *dst = (uint4 *)(out + off[rd]);
     size_t words = (size_t)c * sizeof(DevRecord) / 16;
     for (size_t t = threadIdx.x; t < words; t += blockDim.x) dst[t] = src[t];
 }
 
+// ---- wire form (include/mtr_hip.h): 14 int32 | rep_period unit bytes padded to 4 | rep_period int32 scores ---------
+__device__ __forceinline__ int wire_period(const DevRecord *r) { int p = r->f[3]; return p < 0 ? 0 : (p > MTRC_MAX_PERIOD ? MTRC_MAX_PERIOD : p); }
+__global__ void mtr_k_wire_sizes(const DevRecord *in, const DevRecord *const *src_of, const int32_t *cnt, int max_rec, int n_reads, int64_t *bytes)
+{
+    const int rd = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rd >= n_reads) return;
+    int c = cnt[rd];
+    if (!src_of && c > max_rec) c = max_rec;
+    const DevRecord *src = src_of ? src_of[rd] : in + (size_t)rd * (size_t)max_rec;
+    int64_t b = 0;
+    for (int t = 0; t < c; t++) { const int p = wire_period(src + t); b += 56 + ((p + 3) & ~3) + 4 * p; }
+    bytes[rd] = b;
+}
+__global__ void mtr_k_wire_pack(const DevRecord *in, const DevRecord *const *src_of, const int32_t *cnt, const int64_t *off, int max_rec, int n_reads, uint8_t *out)
+{
+    // one wavefront per read; every piece of a wire record is a whole number of dwords at a dword-aligned offset
+    const int rd = blockIdx.x;
+    if (rd >= n_reads) return;
+    int c = cnt[rd];
+    if (!src_of && c > max_rec) c = max_rec;
+    const DevRecord *src = src_of ? src_of[rd] : in + (size_t)rd * (size_t)max_rec;
+    uint32_t *dst = (uint32_t *)(out + off[rd]);
+    for (int t = 0; t < c; t++) {
+        const DevRecord *r = src + t;
+        const int p = wire_period(r), uw = (p + 3) >> 2;
+        const uint32_t *h = (const uint32_t *)r->f, *u = (const uint32_t *)r->unit, *sc = (const uint32_t *)r->unit_score;
+        for (int q = threadIdx.x; q < 14 + uw + p; q += blockDim.x) {
+            uint32_t v;
+            if (q < 14) v = h[q];
+            else if (q < 14 + uw) {
+                v = u[q - 14];
+                const int keep = p - 4 * (q - 14);                       // bytes of this word that belong to the unit
+                if (keep < 4) v &= (1u << (8 * keep)) - 1u;
+            } else v = sc[q - 14 - uw];
+            dst[q] = v;
+        }
+        dst += 14 + uw + p;
+    }
+}
+
+// status of the resident batch for the calls that read its results
+static mtr_status results_ready(mtr_ctx *ctx, bool allow_dp_failure)
+{
+    { mtr_status w = mtr_wait(ctx); if (w != MTR_OK && !(allow_dp_failure && w == MTR_ERR_DP_TOO_LARGE)) return w; }
+    if (ctx->n_reads <= 0 || (!ctx->ran && !(allow_dp_failure && ctx->run_status == MTR_ERR_DP_TOO_LARGE))) {
+        if (ctx->run_status != MTR_OK) return ctx->run_status;
+        ctx->err = "nothing has been run"; return MTR_ERR_BAD_ARG;
+    }
+    return MTR_OK;
+}
+
+extern "C" mtr_status mtr_get_first_failed_read(const mtr_ctx *ctx, int32_t *out)
+{
+    if (!ctx || !out) return MTR_ERR_BAD_ARG;
+    *out = ctx->first_failed;
+    return MTR_OK;
+}
+
 extern "C" mtr_status mtr_fetch_results(mtr_ctx *ctx, mtr_record **out_records, int32_t **out_counts, int64_t *out_total)
 {
     if (!ctx || !out_records || !out_counts) return MTR_ERR_BAD_ARG;
-    { mtr_status w = mtr_wait(ctx); if (w != MTR_OK) return w; }
-    if (!ctx->ran) { ctx->err = "nothing has been run"; return MTR_ERR_BAD_ARG; }
+    { mtr_status r = results_ready(ctx, false); if (r != MTR_OK) return r; }
     HIPCHK(hipSetDevice(ctx->device));
     const int n = ctx->n_reads;
     int32_t *counts = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
     if (!counts) return MTR_ERR_OOM;
-    HIPCHK(copy_sync(ctx, counts, ctx->d_reccount, (size_t)n * 4, hipMemcpyDeviceToHost));
+    mtr_record *recs = nullptr;
+    auto fail = [&](mtr_status st) { free(counts); free(recs); return st; };
+#define FETCH_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return fail(MTR_ERR_HIP); } } while (0)
+    FETCH_CHK(copy_sync(ctx, counts, ctx->d_reccount, (size_t)n * 4, hipMemcpyDeviceToHost));
     std::vector<int64_t> off((size_t)n + 1, 0);
     for (int i = 0; i < n; i++) off[(size_t)i + 1] = off[(size_t)i] + counts[i];
     const int64_t total = off[(size_t)n];
-    mtr_record *recs = (mtr_record *)malloc(sizeof(mtr_record) * (size_t)std::max<int64_t>(total, 1));
-    if (!recs) { free(counts); return MTR_ERR_OOM; }
+    recs = (mtr_record *)malloc(sizeof(mtr_record) * (size_t)std::max<int64_t>(total, 1));
+    if (!recs) return fail(MTR_ERR_OOM);
     if (total > 0) {
         int64_t *d_off = ctx->d_recoff;
-        HIPCHK(ensure_dev(ctx, ctx->d_out, (size_t)total * sizeof(DevRecord)));
+        FETCH_CHK(ensure_dev(ctx, ctx->d_out, (size_t)total * sizeof(DevRecord)));
         DevRecord *d_out = ctx->d_out;
-        HIPCHK(hipMemcpyAsync(d_off, off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        FETCH_CHK(hipMemcpyAsync(d_off, off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
         const DevRecord *const *srcs = nullptr;
-        { mtr_status st = record_sources(ctx, &srcs); if (st != MTR_OK) { free(counts); free(recs); return st; } }
+        { mtr_status st = record_sources(ctx, &srcs); if (st != MTR_OK) return fail(st); }
         hipLaunchKernelGGL(mtr_k_compact, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->d_records, srcs, ctx->d_reccount, d_off, ctx->max_rec, n, d_out);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(recs, d_out, (size_t)total * sizeof(DevRecord), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        FETCH_CHK(hipGetLastError());
+        FETCH_CHK(hipMemcpyAsync(recs, d_out, (size_t)total * sizeof(DevRecord), hipMemcpyDeviceToHost, ctx->stream));
+        FETCH_CHK(hipStreamSynchronize(ctx->stream));
     }
+#undef FETCH_CHK
     *out_records = recs; *out_counts = counts; if (out_total) *out_total = total;
     return MTR_OK;
+}
+
+// sizes + offsets of the wire form of reads [0, n): counts and per-read byte sizes come to pinned host memory
+static mtr_status wire_layout(mtr_ctx *ctx, int n, const DevRecord *const **srcs_out, int64_t *total_records, int64_t *total_bytes)
+{
+    HIPCHK(ensure_pinned(ctx->h_counts, ctx->h_counts_cap, (size_t)n * 4));
+    HIPCHK(ensure_pinned(ctx->h_sizes, ctx->h_sizes_cap, ((size_t)n + 1) * 8));
+    HIPCHK(ensure_dev(ctx, ctx->d_wire_bytes, (size_t)n * 8)); HIPCHK(ensure_dev(ctx, ctx->d_wire_off, ((size_t)n + 1) * 8));
+    const DevRecord *const *srcs = nullptr;
+    { mtr_status st = record_sources(ctx, &srcs); if (st != MTR_OK) return st; }
+    *srcs_out = srcs;
+    hipLaunchKernelGGL(mtr_k_wire_sizes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_records, srcs, ctx->d_reccount, ctx->max_rec, n, ctx->d_wire_bytes);
+    HIPCHK(hipGetLastError());
+    int32_t *counts = (int32_t *)ctx->h_counts; int64_t *sizes = (int64_t *)ctx->h_sizes;
+    HIPCHK(hipMemcpyAsync(counts, ctx->d_reccount, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(sizes, ctx->d_wire_bytes, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    int64_t recs = 0, off = 0;
+    for (int i = 0; i < n; i++) { recs += counts[i]; const int64_t b = sizes[i]; sizes[i] = off; off += b; }   // in place: sizes -> offsets
+    sizes[n] = off;
+    *total_records = recs; *total_bytes = off;
+    HIPCHK(hipMemcpyAsync(ctx->d_wire_off, sizes, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    return MTR_OK;
+}
+
+extern "C" mtr_status mtr_fetch_results_packed(mtr_ctx *ctx, int32_t n_reads_limit, const uint8_t **out_blob, int64_t *out_bytes,
+                                               const int32_t **out_counts, int64_t *out_total_records)
+{
+    if (!ctx || !out_blob || !out_bytes || !out_counts) return MTR_ERR_BAD_ARG;
+    { mtr_status r = results_ready(ctx, n_reads_limit >= 0); if (r != MTR_OK) return r; }
+    HIPCHK(hipSetDevice(ctx->device));
+    int n = ctx->n_reads;
+    if (n_reads_limit >= 0 && n_reads_limit < n) n = n_reads_limit;
+    if (ctx->run_status == MTR_ERR_DP_TOO_LARGE && (ctx->first_failed < 0 || n > ctx->first_failed)) { ctx->err = "only the reads before the first failed one can be fetched"; return MTR_ERR_DP_TOO_LARGE; }
+    *out_blob = nullptr; *out_bytes = 0; *out_counts = nullptr; if (out_total_records) *out_total_records = 0;
+    if (n == 0) return MTR_OK;
+    const DevRecord *const *srcs = nullptr; int64_t recs = 0, bytes = 0;
+    { mtr_status st = wire_layout(ctx, n, &srcs, &recs, &bytes); if (st != MTR_OK) return st; }
+    HIPCHK(ensure_pinned(ctx->h_blob, ctx->h_blob_cap, (size_t)std::max<int64_t>(bytes, 4)));
+    if (bytes > 0) {
+        HIPCHK(ensure_dev(ctx, ctx->d_wire, (size_t)bytes));
+        hipLaunchKernelGGL(mtr_k_wire_pack, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->d_records, srcs, ctx->d_reccount, ctx->d_wire_off, ctx->max_rec, n, ctx->d_wire);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(ctx->h_blob, ctx->d_wire, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *out_blob = (const uint8_t *)ctx->h_blob; *out_bytes = bytes; *out_counts = (const int32_t *)ctx->h_counts;
+    if (out_total_records) *out_total_records = recs;
+    return MTR_OK;
+}
+
+extern "C" mtr_status mtr_export_packed_device(mtr_ctx *ctx, void *d_dst, int64_t capacity_bytes, int32_t *counts_host,
+                                               int64_t *out_total_records, int64_t *out_bytes)
+{
+    if (!ctx || !counts_host || !out_total_records || !out_bytes) return MTR_ERR_BAD_ARG;
+    { mtr_status r = results_ready(ctx, false); if (r != MTR_OK) return r; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = ctx->n_reads;
+    const DevRecord *const *srcs = nullptr; int64_t recs = 0, bytes = 0;
+    { mtr_status st = wire_layout(ctx, n, &srcs, &recs, &bytes); if (st != MTR_OK) return st; }
+    memcpy(counts_host, ctx->h_counts, (size_t)n * 4);
+    *out_total_records = recs; *out_bytes = bytes;
+    if (bytes == 0) { HIPCHK(hipStreamSynchronize(ctx->stream)); return MTR_OK; }
+    if (!d_dst || bytes > capacity_bytes) { (void)hipStreamSynchronize(ctx->stream); ctx->err = "destination holds " + std::to_string(capacity_bytes) + " bytes, " + std::to_string(bytes) + " needed"; return MTR_ERR_OVERFLOW; }
+    hipLaunchKernelGGL(mtr_k_wire_pack, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->d_records, srcs, ctx->d_reccount, ctx->d_wire_off, ctx->max_rec, n, (uint8_t *)d_dst);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return MTR_OK;
+}
+
+// host-only conversions between the wire form and mtr_record
+extern "C" mtr_status mtr_unpack_records(const uint8_t *blob, int64_t bytes, int64_t n_records, mtr_record *out)
+{
+    if ((!blob && bytes > 0) || (!out && n_records > 0) || bytes < 0 || n_records < 0) return MTR_ERR_BAD_ARG;
+    int64_t o = 0;
+    for (int64_t i = 0; i < n_records; i++) {
+        if (o + MTR_WIRE_HEADER_BYTES > bytes) return MTR_ERR_BAD_ARG;
+        mtr_record *r = out + i;
+        memcpy(r, blob + o, MTR_WIRE_HEADER_BYTES);
+        const int p = r->rep_period;
+        if (p < 0 || p > MTR_MAX_PERIOD) return MTR_ERR_BAD_ARG;
+        const int64_t need = mtr_wire_record_bytes(p);
+        if (o + need > bytes) return MTR_ERR_BAD_ARG;
+        memcpy(r->unit, blob + o + MTR_WIRE_HEADER_BYTES, (size_t)p);
+        r->unit[p] = 0;
+        memcpy(r->unit_score, blob + o + MTR_WIRE_HEADER_BYTES + ((p + 3) & ~3), (size_t)p * 4);
+        o += need;
+    }
+    return o == bytes ? MTR_OK : MTR_ERR_BAD_ARG;
+}
+
+extern "C" int64_t mtr_pack_records(const mtr_record *records, int64_t n_records, uint8_t *out, int64_t capacity)
+{
+    if ((!records && n_records > 0) || n_records < 0 || (!out && capacity > 0)) return -1;
+    int64_t o = 0;
+    for (int64_t i = 0; i < n_records; i++) {
+        const mtr_record *r = records + i;
+        const int p = r->rep_period < 0 ? 0 : (r->rep_period > MTR_MAX_PERIOD ? MTR_MAX_PERIOD : r->rep_period);
+        const int64_t need = mtr_wire_record_bytes(p);
+        if (o + need > capacity) return -1;
+        memcpy(out + o, r, MTR_WIRE_HEADER_BYTES);
+        const int up = (p + 3) & ~3;
+        memcpy(out + o + MTR_WIRE_HEADER_BYTES, r->unit, (size_t)p);
+        memset(out + o + MTR_WIRE_HEADER_BYTES + p, 0, (size_t)(up - p));
+        memcpy(out + o + MTR_WIRE_HEADER_BYTES + up, r->unit_score, (size_t)p * 4);
+        o += need;
+    }
+    return o;
 }
 
 // Multi-GPU plumbing: compact the records of the last run into caller-owned DEVICE memory (e.g. a torch
@@ -725,8 +971,7 @@ extern "C" mtr_status mtr_fetch_results(mtr_ctx *ctx, mtr_record **out_records, 
 extern "C" mtr_status mtr_export_records_device(mtr_ctx *ctx, void *d_dst, int64_t capacity_records, int32_t *counts_host, int64_t *out_total)
 {
     if (!ctx || !counts_host || !out_total) return MTR_ERR_BAD_ARG;
-    { mtr_status w = mtr_wait(ctx); if (w != MTR_OK) return w; }
-    if (!ctx->ran) { ctx->err = "nothing has been run"; return MTR_ERR_BAD_ARG; }
+    { mtr_status r = results_ready(ctx, false); if (r != MTR_OK) return r; }
     HIPCHK(hipSetDevice(ctx->device));
     const int n = ctx->n_reads;
     HIPCHK(copy_sync(ctx, counts_host, ctx->d_reccount, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -831,9 +1076,9 @@ extern "C" mtr_status mtr_test_wrap_dp(mtr_ctx *ctx, int32_t n_tasks, const int3
     int waves = pick_waves(ctx, n_tasks, 8, per_wave, &total);
     DBG("test_wrap_dp: %d tasks, cells %zu, waves %d, scratch %zu", n_tasks, cells, waves, total);
     mtr_status s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;
-    int32_t *d_i32 = nullptr; uint8_t *d_units = nullptr; int32_t *d_out = nullptr;
     const size_t nt = (size_t)n_tasks;
-    HIPCHK(hipMalloc(&d_i32, (nt * 7 + 1) * 4)); HIPCHK(hipMalloc(&d_units, (size_t)unit_off[n_tasks] + 16)); HIPCHK(hipMalloc(&d_out, nt * 8 * 4));
+    HIPCHK(ensure_dev(ctx, ctx->d_t_i32, (nt * 7 + 1) * 4)); HIPCHK(ensure_dev(ctx, ctx->d_t_units, (size_t)unit_off[n_tasks] + 16)); HIPCHK(ensure_dev(ctx, ctx->d_t_out, nt * 8 * 4));
+    int32_t *d_i32 = ctx->d_t_i32; uint8_t *d_units = ctx->d_t_units; int32_t *d_out = ctx->d_t_out;
     int32_t *d_rd = d_i32, *d_qs = d_i32 + nt, *d_qe = d_i32 + 2 * nt, *d_g = d_i32 + 3 * nt, *d_m = d_i32 + 4 * nt, *d_d = d_i32 + 5 * nt, *d_uo = d_i32 + 6 * nt;
     HIPCHK(copy_sync(ctx, d_rd, read_idx, nt * 4, hipMemcpyHostToDevice)); HIPCHK(copy_sync(ctx, d_qs, query_start, nt * 4, hipMemcpyHostToDevice));
     HIPCHK(copy_sync(ctx, d_qe, query_end, nt * 4, hipMemcpyHostToDevice)); HIPCHK(copy_sync(ctx, d_g, gain, nt * 4, hipMemcpyHostToDevice));
@@ -856,7 +1101,6 @@ extern "C" mtr_status mtr_test_wrap_dp(mtr_ctx *ctx, int32_t n_tasks, const int3
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->kt[1].ms = ms; ctx->kt[1].launches = 1;
     HIPCHK(copy_sync(ctx, ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
     HIPCHK(copy_sync(ctx, out8, d_out, nt * 8 * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_i32); (void)hipFree(d_units); (void)hipFree(d_out);
     return check_status(ctx);
 }
 
@@ -865,7 +1109,7 @@ extern "C" mtr_status mtr_alignments(mtr_ctx *ctx, int32_t n, const int32_t *rea
 {
     if (!ctx || n < 0 || (n > 0 && (!read_idx || !records)) || !out_ops || !out_off || !out_end) return MTR_ERR_BAD_ARG;
     if (ctx->n_reads <= 0) { ctx->err = "no batch uploaded"; return MTR_ERR_BAD_ARG; }
-    { mtr_status w = mtr_wait(ctx); if (w != MTR_OK) return w; }
+    { mtr_status w = mtr_wait(ctx); if (w != MTR_OK && w != MTR_ERR_DP_TOO_LARGE) return w; }   // after a DP failure: the reads before it are still printed
     HIPCHK(hipSetDevice(ctx->device));
     int64_t *off = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n + 1));
     if (!off) return MTR_ERR_OOM;
@@ -895,13 +1139,13 @@ extern "C" mtr_status mtr_alignments(mtr_ctx *ctx, int32_t n, const int32_t *rea
     size_t total = 0;
     const int waves = pick_waves(ctx, n, 8, per_wave, &total);
     mtr_status s = ensure_scratch(ctx, total); if (s != MTR_OK) { free(off); return s; }
-    int32_t *d_i32 = nullptr, *d_len = nullptr, *d_ends = nullptr; uint8_t *d_units = nullptr, *d_ops = nullptr; int64_t *d_off = nullptr;
     int32_t *ends = nullptr;
     const size_t ops_bytes = (size_t)cap_off[nt];
-    auto fail = [&](mtr_status st) { (void)hipFree(d_i32); (void)hipFree(d_len); (void)hipFree(d_ends); (void)hipFree(d_units); (void)hipFree(d_ops); (void)hipFree(d_off); free(off); free(ends); return st; };
+    auto fail = [&](mtr_status st) { free(off); free(ends); return st; };
 #define ALN_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return fail(MTR_ERR_HIP); } } while (0)
-    ALN_CHK(hipMalloc(&d_i32, h.size() * 4)); ALN_CHK(hipMalloc(&d_len, nt * 4)); ALN_CHK(hipMalloc(&d_units, units.size() + 16));
-    ALN_CHK(hipMalloc(&d_ops, ops_bytes + 16)); ALN_CHK(hipMalloc(&d_off, (nt + 1) * 8)); ALN_CHK(hipMalloc(&d_ends, nt * 8));
+    ALN_CHK(ensure_dev(ctx, ctx->d_al_i32, h.size() * 4)); ALN_CHK(ensure_dev(ctx, ctx->d_al_len, nt * 4)); ALN_CHK(ensure_dev(ctx, ctx->d_al_units, units.size() + 16));
+    ALN_CHK(ensure_dev(ctx, ctx->d_al_ops, ops_bytes + 16)); ALN_CHK(ensure_dev(ctx, ctx->d_al_off, (nt + 1) * 8)); ALN_CHK(ensure_dev(ctx, ctx->d_al_ends, nt * 8));
+    int32_t *d_i32 = ctx->d_al_i32, *d_len = ctx->d_al_len, *d_ends = ctx->d_al_ends; uint8_t *d_units = ctx->d_al_units, *d_ops = ctx->d_al_ops; int64_t *d_off = ctx->d_al_off;
     ALN_CHK(hipMemcpyAsync(d_i32, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     ALN_CHK(hipMemcpyAsync(d_units, units.data(), units.size(), hipMemcpyHostToDevice, ctx->stream));
     ALN_CHK(hipMemcpyAsync(d_off, cap_off.data(), (nt + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -925,12 +1169,11 @@ extern "C" mtr_status mtr_alignments(mtr_ctx *ctx, int32_t n, const int32_t *rea
     ALN_CHK(hipMemcpyAsync(raw.data(), d_ops, ops_bytes, hipMemcpyDeviceToHost, ctx->stream));
     ALN_CHK(hipStreamSynchronize(ctx->stream));
 #undef ALN_CHK
-    { mtr_status st = check_status(ctx); if (st != MTR_OK) return fail(st); }
+    { mtr_status st = check_status(ctx); if (st != MTR_OK && !(st == MTR_ERR_DP_TOO_LARGE && ctx->run_status == MTR_ERR_DP_TOO_LARGE)) return fail(st); }
     for (int t = 0; t < n; t++) off[(size_t)t + 1] = off[(size_t)t] + len[(size_t)t];
     uint8_t *ops = (uint8_t *)malloc((size_t)std::max<int64_t>(off[nt], 1));
     if (!ops) return fail(MTR_ERR_OOM);
     for (int t = 0; t < n; t++) memcpy(ops + off[(size_t)t], raw.data() + cap_off[(size_t)t], (size_t)len[(size_t)t]);
-    (void)hipFree(d_i32); (void)hipFree(d_len); (void)hipFree(d_ends); (void)hipFree(d_units); (void)hipFree(d_ops); (void)hipFree(d_off);
     for (int t = 0; t < n; t++) ends[2 * t] = records[t].rep_start - 1 + ends[2 * t];       // window row -> read position
     *out_ops = ops; *out_off = off; *out_end = ends;
     return MTR_OK;

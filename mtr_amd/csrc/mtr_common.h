@@ -208,6 +208,7 @@ struct K2Args {
     DevRecord *records; int32_t max_rec_per_read; int32_t *rec_count;   // rec_count = records FOUND (may exceed the slots: the host reruns such reads)
     const int64_t *rec_base;       // slot index of read rd's first record, or nullptr = rd * max_rec_per_read
     int32_t *status; unsigned int *work_counter; unsigned long long *counters;
+    int32_t *fail_read;            // atomicMin of the index of a read whose DP exceeded WrapDPsize (the reference exits there)
     int32_t *trace; int32_t trace_cap; unsigned int *trace_n; int32_t trace_mask;   // bit t = record events of type t
     int32_t dp16_max_rows;         // DPs of up to this many rows may use the 16-bit kernels (tests set 0 to force the 32-bit ones)
 };

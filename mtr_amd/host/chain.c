@@ -21,42 +21,53 @@ static int ev_cmp(const void *a, const void *b)
     return x->seq - y->seq;
 }
 
-int mtrh_chain(const mtr_record *recs, int n, int *chain)
+int mtrh_chain(const mtrh_rec *recs, int n, int *chain)
 {
     if (n <= 0) return 0;
-    event *ev = (event *)malloc(sizeof(event) * 2 * (size_t)n);
-    int *score = (int *)malloc(sizeof(int) * (size_t)n), *pred = (int *)malloc(sizeof(int) * (size_t)n);
-    int *Y = (int *)malloc(sizeof(int) * (size_t)n);
+    if (n == 1) {                                              /* a single alignment is its own chain if it enters the sweep at all */
+        if (recs[0].h[MTRH_REP_START] + MTRH_OVERLAP <= recs[0].h[MTRH_REP_END]) { chain[0] = 0; return 1; }
+        return 0;
+    }
+    /* small reads (the common case) work on the stack */
+    enum { SMALL = 32 };
+    event ev_s[2 * SMALL]; int score_s[SMALL], pred_s[SMALL], Y_s[SMALL], st_s[SMALL], en_s[SMALL];
+    const int small = n <= SMALL;
+    event *ev = small ? ev_s : (event *)malloc(sizeof(event) * 2 * (size_t)n);
+    int *score = small ? score_s : (int *)malloc(sizeof(int) * (size_t)n), *pred = small ? pred_s : (int *)malloc(sizeof(int) * (size_t)n);
+    int *Y = small ? Y_s : (int *)malloc(sizeof(int) * (size_t)n);
+    int *rs = small ? st_s : (int *)malloc(sizeof(int) * (size_t)n), *re = small ? en_s : (int *)malloc(sizeof(int) * (size_t)n);
     int ne = 0, ny = 0;
     for (int i = 0; i < n; i++) {
-        score[i] = recs[i].num_matches; pred[i] = -1;
-        if (recs[i].rep_start + MTRH_OVERLAP <= recs[i].rep_end) {
-            ev[ne].key = recs[i].rep_start; ev[ne].idx = i; ev[ne].seq = ne; ne++;
-            ev[ne].key = recs[i].rep_end - MTRH_OVERLAP; ev[ne].idx = i; ev[ne].seq = ne; ne++;
+        score[i] = recs[i].h[MTRH_MATCHES]; pred[i] = -1; rs[i] = recs[i].h[MTRH_REP_START]; re[i] = recs[i].h[MTRH_REP_END];
+        if (rs[i] + MTRH_OVERLAP <= re[i]) {
+            ev[ne].key = rs[i]; ev[ne].idx = i; ev[ne].seq = ne; ne++;
+            ev[ne].key = re[i] - MTRH_OVERLAP; ev[ne].idx = i; ev[ne].seq = ne; ne++;
         }
     }
-    qsort(ev, (size_t)ne, sizeof(event), ev_cmp);
+    if (ne <= 16) {                                            /* insertion sort: stable, no call through a function pointer */
+        for (int a = 1; a < ne; a++) { event t = ev[a]; int b = a; while (b > 0 && ev_cmp(&ev[b - 1], &t) > 0) { ev[b] = ev[b - 1]; b--; } ev[b] = t; }
+    } else qsort(ev, (size_t)ne, sizeof(event), ev_cmp);
     for (int e = 0; e < ne; e++) {
         const int a = ev[e].idx;
-        if (ev[e].key == recs[a].rep_start) {                 /* Alignment::isStart */
-            const int lim = recs[a].rep_start + MTRH_OVERLAP;
+        if (ev[e].key == rs[a]) {                 /* Alignment::isStart */
+            const int lim = rs[a] + MTRH_OVERLAP;
             int p = -1;
             for (int t = 0; t < ny; t++) {                    /* Y is sorted by end: the last one within the limit */
-                if (recs[Y[t]].rep_end <= lim) p = Y[t];
+                if (re[Y[t]] <= lim) p = Y[t];
                 else break;
             }
             if (p >= 0) { pred[a] = p; score[a] += score[p]; }
         } else {
             int better = 0;
-            for (int t = 0; t < ny && recs[Y[t]].rep_end <= recs[a].rep_end; t++)
+            for (int t = 0; t < ny && re[Y[t]] <= re[a]; t++)
                 if (score[Y[t]] > score[a]) better = 1;
             if (better) continue;
             int pos = ny;
-            while (pos > 0 && recs[Y[pos - 1]].rep_end > recs[a].rep_end) pos--;
+            while (pos > 0 && re[Y[pos - 1]] > re[a]) pos--;
             memmove(Y + pos + 1, Y + pos, sizeof(int) * (size_t)(ny - pos));
             Y[pos] = a; ny++;
             for (int t = 0; t < ny; t++)
-                if (recs[Y[t]].rep_end >= recs[a].rep_end && score[Y[t]] < score[a]) {
+                if (re[Y[t]] >= re[a] && score[Y[t]] < score[a]) {
                     memmove(Y + t, Y + t + 1, sizeof(int) * (size_t)(ny - t - 1));
                     ny--;                                      /* t now names the successor; the loop's t++ skips it */
                 }
@@ -68,6 +79,6 @@ int mtrh_chain(const mtr_record *recs, int n, int *chain)
         int p = len;
         for (int a = Y[ny - 1]; a >= 0; a = pred[a]) chain[--p] = a;
     }
-    free(ev); free(score); free(pred); free(Y);
+    if (!small) { free(ev); free(score); free(pred); free(Y); free(rs); free(re); }
     return len;
 }

@@ -1,96 +1,236 @@
-/* fasta.c — batch FASTA reader keeping the reference's quirks (handle_one_file.c:169-269). */
+/* fasta.c — the reference's FASTA reader (handle_one_file.c:169-269) restated over a memory-mapped file, so that a file
+ * can be cut at record boundaries and its pieces parsed on several threads / by several processes.
+ *
+ * What the reference does, and what is kept:
+ *   - it reads with fgets(s, BLK = 4096, fp): a "window" is at most 4095 characters and ends after a newline; a line
+ *     longer than that is seen as several windows (:208);
+ *   - a window whose first character is '>' is a header: the ID is what follows up to NUL / LF / CR (:211-236);
+ *   - any other window is sequence: characters up to the first NUL / LF / CR are bases, the rest of the window is
+ *     ignored; ACGT/acgt only, anything else is fatal ("Invalid character", :169-188); a read that reaches
+ *     MAX_INPUT_LENGTH bases is fatal (:241-246);
+ *   - sequence before the first header joins the first record (:213-221); a record without bases ends the input (:283).
+ * A header at a line start is always the start of a window, so cutting the file at "\n>" changes nothing.
+ */
+#define _GNU_SOURCE
 #include "mtr_host.h"
+#include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
-
-struct mtrh_fasta {
-    FILE *fp;
-    char  buf[MTRH_BLK];
-    char *pending_id;       /* header already consumed for the next record */
-    int   have_header, done;
-};
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 static void *xrealloc(void *p, size_t n)
 {
-    void *q = realloc(p, n);
+    void *q = realloc(p, n ? n : 1);
     if (!q) { fprintf(stderr, "cannot allocate %zu bytes\n", n); exit(EXIT_FAILURE); }
     return q;
 }
 
-static char *header_id(const char *line)
+int mtrh_file_open(mtrh_file *f, const char *path)
 {
-    size_t i = 1;
-    while (line[i] && line[i] != '\n' && line[i] != '\r') i++;
-    char *id = (char *)xrealloc(NULL, i);
-    memcpy(id, line + 1, i - 1);
-    id[i - 1] = 0;
-    return id;
+    memset(f, 0, sizeof *f);
+    f->path = path; f->fd = open(path, O_RDONLY);
+    struct stat st;
+    if (f->fd < 0 || fstat(f->fd, &st) != 0) {
+        fprintf(stderr, "fatal error: cannot open %s\n", path); fflush(stderr);     /* handle_one_file.c:192-196 */
+        if (f->fd >= 0) close(f->fd);
+        f->fd = -1;
+        return 1;
+    }
+    f->size = (size_t)st.st_size;
+    if (f->size > 0) {
+        void *m = mmap(NULL, f->size, PROT_READ, MAP_PRIVATE, f->fd, 0);
+        if (m == MAP_FAILED) { fprintf(stderr, "fatal error: cannot open %s\n", path); close(f->fd); f->fd = -1; return 1; }
+        f->map = (const char *)m;
+        (void)madvise(m, f->size, MADV_SEQUENTIAL);
+    }
+    return 0;
 }
 
-mtrh_fasta *mtrh_fasta_open(const char *path)
+void mtrh_file_close(mtrh_file *f)
 {
-    FILE *fp = fopen(path, "r");
-    if (!fp) { fprintf(stderr, "fatal error: cannot open %s\n", path); fflush(stderr); exit(EXIT_FAILURE); }
-    mtrh_fasta *f = (mtrh_fasta *)calloc(1, sizeof(*f));
-    f->fp = fp;
-    return f;
+    if (f->map) munmap((void *)f->map, f->size);
+    if (f->fd >= 0) close(f->fd);
+    f->map = NULL; f->fd = -1; f->size = 0;
 }
 
-void mtrh_fasta_close(mtrh_fasta *f) { if (f) { fclose(f->fp); free(f->pending_id); free(f); } }
-void mtrh_read_free(mtrh_read *r) { free(r->id); free(r->codes); r->id = NULL; r->codes = NULL; r->len = 0; }
+size_t *mtrh_plan_chunks(const mtrh_file *f, int n_target, int *n_chunks)
+{
+    if (n_target < 1) n_target = 1;
+    size_t n = 0;
+    size_t *off = (size_t *)xrealloc(NULL, sizeof(size_t) * ((size_t)n_target + 2));
+    off[n++] = 0;
+    /* bases before the first header join the first record (:213-221): that header stays in the first piece */
+    size_t first_header = 0;
+    if (f->size > 0 && f->map[0] != '>') {
+        const char *p = f->map, *end = f->map + f->size;
+        first_header = f->size;
+        while (p < end) {
+            const char *q = (const char *)memchr(p, '\n', (size_t)(end - p));
+            if (!q || q + 1 >= end) break;
+            if (q[1] == '>') { first_header = (size_t)(q + 1 - f->map); break; }
+            p = q + 1;
+        }
+    }
+    for (int k = 1; k < n_target; k++) {
+        size_t target = (size_t)((unsigned __int128)f->size * (unsigned)k / (unsigned)n_target);
+        if (target <= off[n - 1]) target = off[n - 1] + 1;
+        if (target <= first_header) target = first_header + 1;
+        if (target >= f->size) break;
+        /* the first header at a line start at or after target (the '\n' before it may sit at target - 1) */
+        const char *p = f->map + target - 1, *end = f->map + f->size;
+        size_t cut = f->size;
+        while (p < end) {
+            const char *q = (const char *)memchr(p, '\n', (size_t)(end - p));
+            if (!q || q + 1 >= end) break;
+            if (q[1] == '>') { cut = (size_t)(q + 1 - f->map); break; }
+            p = q + 1;
+        }
+        if (cut >= f->size) break;
+        if (cut > off[n - 1]) off[n++] = cut;
+    }
+    off[n] = f->size;
+    *n_chunks = (int)n;
+    return off;
+}
 
-/* base code of a character: 0..3 for ACGT/acgt, 0xFE for the characters that end a line (NUL, LF, CR),
- * 0xFF for everything else (fatal, handle_one_file.c:169-188) */
+/* base code of a character: 0..3 for ACGT/acgt, 0xFE for what ends a window's sequence (NUL, LF, CR), 0xFF = fatal */
 static uint8_t code_of[256];
 static void init_codes(void)
 {
-    if (code_of['C'] == 1) return;
-    memset(code_of, 0xFF, sizeof code_of);
-    code_of[0] = code_of['\n'] = code_of['\r'] = 0xFE;
-    code_of['A'] = code_of['a'] = 0; code_of['C'] = code_of['c'] = 1; code_of['G'] = code_of['g'] = 2; code_of['T'] = code_of['t'] = 3;
+    static int done;
+    if (done) return;
+    uint8_t t[256];
+    memset(t, 0xFF, sizeof t);
+    t[0] = t['\n'] = t['\r'] = 0xFE;
+    t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3;
+    memcpy(code_of, t, sizeof t);
+    __atomic_store_n(&done, 1, __ATOMIC_RELEASE);
 }
 
-/* one record; returns 0 at the end of input or at the first empty record (handle_one_file.c:283) */
-static int next_read(mtrh_fasta *f, mtrh_read *out)
+typedef struct {
+    mtrh_batch *head, *cur;
+    int64_t cap_reads, cap_codes, cap_words, n_codes;
+    int max_reads; int64_t max_bases;
+} builder;
+
+static mtrh_batch *batch_new(void)
 {
-    if (f->done) return 0;
+    mtrh_batch *b = (mtrh_batch *)calloc(1, sizeof *b);
+    if (!b) { fprintf(stderr, "cannot allocate a batch\n"); exit(EXIT_FAILURE); }
+    return b;
+}
+
+static void builder_open(builder *B)
+{
+    mtrh_batch *b = batch_new();
+    if (B->cur) B->cur->next = b; else B->head = b;
+    B->cur = b; B->cap_reads = B->cap_codes = B->cap_words = B->n_codes = 0;
+}
+
+/* room for one more read of up to `more` further bases in the current batch's code array */
+static uint8_t *codes_room(builder *B, int64_t have, int64_t more)
+{
+    mtrh_batch *b = B->cur;
+    if (B->n_codes + have + more > B->cap_codes) {
+        int64_t c = B->cap_codes ? B->cap_codes * 2 : (1 << 20);
+        while (c < B->n_codes + have + more) c *= 2;
+        b->codes = (uint8_t *)xrealloc(b->codes, (size_t)c); B->cap_codes = c;
+    }
+    return b->codes + B->n_codes;
+}
+
+static void read_done(builder *B, int64_t len, const char *id, int32_t id_len)
+{
+    mtrh_batch *b = B->cur;
+    if (b->n == B->cap_reads) {
+        const int64_t c = B->cap_reads ? B->cap_reads * 2 : 4096;
+        b->lens = (int32_t *)xrealloc(b->lens, sizeof(int32_t) * (size_t)c); b->offs = (int64_t *)xrealloc(b->offs, sizeof(int64_t) * (size_t)c);
+        b->woff = (int64_t *)xrealloc(b->woff, sizeof(int64_t) * (size_t)c);
+        b->ids = (const char **)xrealloc((void *)b->ids, sizeof(char *) * (size_t)c); b->id_lens = (int32_t *)xrealloc(b->id_lens, sizeof(int32_t) * (size_t)c);
+        B->cap_reads = c;
+    }
+    const int64_t nw = mtr_packed_words((int32_t)len);
+    if (b->n_words + nw > B->cap_words) {
+        int64_t c = B->cap_words ? B->cap_words * 2 : (1 << 18);
+        while (c < b->n_words + nw) c *= 2;
+        b->packed = (uint32_t *)xrealloc(b->packed, sizeof(uint32_t) * (size_t)c); B->cap_words = c;
+    }
+    const int i = b->n++;
+    b->lens[i] = (int32_t)len; b->offs[i] = B->n_codes; b->woff[i] = b->n_words; b->ids[i] = id; b->id_lens[i] = id_len;
+    (void)mtr_pack_read(b->codes + B->n_codes, (int32_t)len, b->packed + b->n_words);    /* codes are 0..3 by construction */
+    b->n_words += nw; B->n_codes += len;
+    if (b->n >= B->max_reads || B->n_codes >= B->max_bases) builder_open(B);
+}
+
+mtrh_batch *mtrh_parse_chunk(const mtrh_file *f, size_t begin, size_t end, int max_reads, int64_t max_bases)
+{
     init_codes();
-    uint8_t *codes = NULL; size_t n = 0, cap = 0;
-    char *id = f->pending_id; f->pending_id = NULL;
-    while (fgets(f->buf, MTRH_BLK, f->fp)) {
-        const unsigned char *s = (const unsigned char *)f->buf;
-        if (s[0] == '>') {
-            if (!f->have_header) { f->have_header = 1; id = header_id(f->buf); continue; }
-            f->pending_id = header_id(f->buf);
-            if (n == 0) { f->done = 1; free(id); free(codes); return 0; }
-            out->id = id; out->codes = codes; out->len = (int32_t)n; out->after[0] = out->after[1] = 0;
-            return 1;
+    builder B; memset(&B, 0, sizeof B);
+    B.max_reads = max_reads > 0 ? max_reads : 16384; B.max_bases = max_bases > 0 ? max_bases : ((int64_t)512 << 20);
+    builder_open(&B);
+    const unsigned char *p = (const unsigned char *)f->map + begin, *e = (const unsigned char *)f->map + end;
+    const char *id = NULL; int32_t id_len = 0;        /* ID of the record being read ("" until a header was seen) */
+    int have_header = 0;                               /* the first header opens the record; at the start of the file bases may
+                                                        * precede it and join that record (:213-221); a chunk that starts
+                                                        * inside the file starts at a header */
+    int64_t n = 0;                                     /* bases of the record being read */
+    uint8_t *dst = codes_room(&B, 0, MTRH_BLK);
+    int end_status = MTRH_END_NONE; char bad = 0;
+    while (p < e) {
+        /* one fgets window: up to 4095 characters, through the newline if it comes earlier */
+        size_t wl = (size_t)(e - p) < (size_t)(MTRH_BLK - 1) ? (size_t)(e - p) : (size_t)(MTRH_BLK - 1);
+        const unsigned char *nl = (const unsigned char *)memchr(p, '\n', wl);
+        if (nl) wl = (size_t)(nl - p) + 1;
+        const unsigned char *wend = p + wl;
+        if (p[0] == '>') {
+            const unsigned char *q = p + 1;
+            while (q < wend && *q != 0 && *q != '\n' && *q != '\r') q++;
+            const char *nid = (const char *)p + 1; const int32_t nid_len = (int32_t)(q - (p + 1));
+            if (!have_header) { have_header = 1; id = nid; id_len = nid_len; p = wend; continue; }   /* the first header: keep feeding the same record */
+            if (n == 0) { end_status = MTRH_END_EMPTY; break; }
+            read_done(&B, n, id ? id : "", id ? id_len : 0);
+            id = nid; id_len = nid_len; n = 0;
+            dst = codes_room(&B, 0, MTRH_BLK);
+            p = wend;
+            continue;
         }
-        if (n + MTRH_BLK > cap) { cap = cap ? cap * 2 : 4096; if (cap < n + MTRH_BLK) cap = n + MTRH_BLK; codes = (uint8_t *)xrealloc(codes, cap); }
-        uint8_t *d = codes + n;
-        uint8_t c;
-        while ((c = code_of[*s]) <= 3) { *d++ = c; s++; }
-        n = (size_t)(d - codes);
-        if (MTR_MAX_INPUT_LENGTH <= (int64_t)n) {       /* the reference stops at the base that reaches the limit (before a later bad character) */
-            fprintf(stderr, "fatal error: The length %d is tentatively at most %i.\nread ID = %s\nSet MAX_INPUT_LENGTH to a larger value", MTR_MAX_INPUT_LENGTH, MTR_MAX_INPUT_LENGTH, id ? id : "");
-            exit(EXIT_FAILURE);
-        }
-        if (c == 0xFF) { fprintf(stderr, "Invalid character: %c \n", (char)*s); exit(EXIT_FAILURE); }
+        dst = codes_room(&B, n, (int64_t)wl) + n;
+        const unsigned char *s = p; uint8_t c; uint8_t *d = dst;
+        while (s < wend && (c = code_of[*s]) <= 3) { *d++ = c; s++; }
+        n += (int64_t)(d - dst);
+        if (MTR_MAX_INPUT_LENGTH <= n) { end_status = MTRH_END_TOOLONG; break; }   /* the reference stops at the base that reaches the limit */
+        if (s < wend && code_of[*s] == 0xFF) { end_status = MTRH_END_BADCHAR; bad = (char)*s; break; }
+        p = wend;
     }
-    f->done = 1;
-    if (n == 0) { free(id); free(codes); return 0; }
-    if (!id) { id = (char *)xrealloc(NULL, 1); id[0] = 0; }
-    out->id = id; out->codes = codes; out->len = (int32_t)n; out->after[0] = out->after[1] = 0;
-    return 1;
+    if (end_status == MTRH_END_NONE) {
+        /* the end of the chunk closes the record being read: the next chunk starts with a header (or the file ends,
+         * :251-267); a record without bases ends the input (:283) */
+        if (n > 0) read_done(&B, n, id ? id : "", id ? id_len : 0);
+        else end_status = MTRH_END_EMPTY;
+    }
+    /* the status belongs to the last batch that holds reads (or the only, empty one) */
+    mtrh_batch *tail = B.head;
+    for (mtrh_batch *b = B.head; b; b = b->next) if (b->n > 0 || b == B.head) tail = b;
+    for (mtrh_batch *b = tail->next; b; ) { mtrh_batch *nx = b->next; b->next = NULL; mtrh_batch_free(b); b = nx; }
+    tail->next = NULL;
+    tail->end = end_status; tail->bad_char = bad;
+    if (end_status == MTRH_END_TOOLONG) {
+        /* the reference prints currentRead->ID here, which still holds the ID of the record BEFORE the one being read
+         * (:243; it is set when a record is returned, :226-229); nothing before the first record */
+        tail->end_id = NULL; tail->end_id_len = 0;
+        if (tail->n > 0) { tail->end_id = tail->ids[tail->n - 1]; tail->end_id_len = tail->id_lens[tail->n - 1]; }
+    }
+    return B.head;
 }
 
-int mtrh_fasta_next_batch(mtrh_fasta *f, mtrh_read *out, int max_reads, int64_t max_bases)
+void mtrh_batch_free(mtrh_batch *b)
 {
-    int n = 0; int64_t bases = 0;
-    while (n < max_reads && bases < max_bases) {
-        if (!next_read(f, &out[n])) break;
-        bases += out[n].len;
-        n++;
+    while (b) {
+        mtrh_batch *nx = b->next;
+        free(b->lens); free(b->offs); free(b->codes); free(b->woff); free(b->packed); free((void *)b->ids); free(b->id_lens); free(b->id_store);
+        free(b);
+        b = nx;
     }
-    return n;
 }

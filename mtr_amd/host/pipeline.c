@@ -1,0 +1,395 @@
+/* pipeline.c — the run of one rank: plan the chunks of the input file(s), parse the chunks this rank owns on parser
+ * threads, and push their batches through two device contexts in turn, so that packing + upload + launch of batch b+1
+ * and fetch (+ alignments) of batch b overlap the kernels.  Replaces the per-read loop of handle_one_file.c:271-293.
+ *
+ * Ownership of chunks: one file -> chunk c belongs to rank c % world and round c / world (a round is what the launcher
+ * gathers together); several files (test_multiple_TRs/test.sh: one read per file, 2.6-140 kb) -> longest first to the
+ * least loaded rank, one round.
+ */
+#define _GNU_SOURCE
+#include "mtr_host.h"
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+#define BATCH_READS 16384
+#define BATCH_BASES ((int64_t)512 << 20)
+#define CHUNK_BYTES ((size_t)24 << 20)         /* ~12 000 reads of 2 kb: one device batch */
+#define PARSE_AHEAD 3
+#define RESULT_QUEUE 4
+
+typedef struct { int file; size_t begin, end; int owner, round; } chunk_t;
+
+struct mtrh_run {
+    mtrh_opts o; mtrh_engine eng;
+    int n_files; mtrh_file *files;
+    int n_chunks, n_rounds; chunk_t *chunks;
+    int n_list; int *list;                     /* the chunks this rank parses, ascending (owned ones; with -B also those before them) */
+    mtrh_batch **parsed; int *pstate;          /* per list entry */
+    int next_parse, consumed;
+    pthread_mutex_t mu; pthread_cond_t cv_parse, cv_res;
+    int n_parsers; pthread_t parsers[16], device;
+    mtrh_result *queue[RESULT_QUEUE]; int q_head, q_n, device_done, stopping;
+    double t_parse_wait, t_submit, t_fetch, t_kernel; long long queries;
+};
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+/* ---- plan ------------------------------------------------------------------------------------------------------------- */
+static int cmp_size_desc(const void *a, const void *b)
+{
+    const chunk_t *x = *(const chunk_t *const *)a, *y = *(const chunk_t *const *)b;
+    const size_t sx = x->end - x->begin, sy = y->end - y->begin;
+    if (sx != sy) return sx > sy ? -1 : 1;
+    return x < y ? -1 : 1;
+}
+
+static void plan(mtrh_run *r)
+{
+    const int world = r->o.world > 0 ? r->o.world : 1;
+    const size_t cb = r->o.chunk_bytes ? r->o.chunk_bytes : CHUNK_BYTES;
+    int cap = 0;
+    for (int f = 0; f < r->n_files; f++) cap += (int)(r->files[f].size / cb) + world + 2;
+    r->chunks = (chunk_t *)calloc((size_t)cap, sizeof(chunk_t));
+    for (int f = 0; f < r->n_files; f++) {
+        /* a multiple of the number of ranks, so that the last round is a full one */
+        size_t want = (r->files[f].size + cb - 1) / cb;
+        if (want < 1) want = 1;
+        if (r->n_files == 1 && world > 1) want = (want + (size_t)world - 1) / (size_t)world * (size_t)world;
+        int nc = 0;
+        size_t *off = mtrh_plan_chunks(&r->files[f], (int)want, &nc);
+        for (int c = 0; c < nc; c++) { chunk_t *k = &r->chunks[r->n_chunks++]; k->file = f; k->begin = off[c]; k->end = off[c + 1]; }
+        free(off);
+    }
+    if (!r->o.lpt) {
+        for (int c = 0; c < r->n_chunks; c++) { r->chunks[c].owner = c % world; r->chunks[c].round = c / world; }
+        r->n_rounds = (r->n_chunks + world - 1) / world;
+    } else {
+        /* longest processing time first: a read's cost grows faster than its length (the DPs of a range are rows x unit) */
+        chunk_t **ord = (chunk_t **)malloc(sizeof(chunk_t *) * (size_t)r->n_chunks);
+        double *load = (double *)calloc((size_t)world, sizeof(double));
+        for (int c = 0; c < r->n_chunks; c++) ord[c] = &r->chunks[c];
+        qsort(ord, (size_t)r->n_chunks, sizeof(chunk_t *), cmp_size_desc);
+        for (int c = 0; c < r->n_chunks; c++) {
+            int best = 0;
+            for (int k = 1; k < world; k++) if (load[k] < load[best]) best = k;
+            ord[c]->owner = best; ord[c]->round = 0;
+            load[best] += pow((double)(ord[c]->end - ord[c]->begin), 1.5);
+        }
+        r->n_rounds = r->n_chunks > 0 ? 1 : 0;
+        free(ord); free(load);
+    }
+}
+
+/* ---- parser threads ----------------------------------------------------------------------------------------------------- */
+static void *parser_main(void *arg)
+{
+    mtrh_run *r = (mtrh_run *)arg;
+    for (;;) {
+        pthread_mutex_lock(&r->mu);
+        while (!r->stopping && r->next_parse < r->n_list && r->next_parse >= r->consumed + PARSE_AHEAD + r->n_parsers) pthread_cond_wait(&r->cv_parse, &r->mu);
+        if (r->stopping || r->next_parse >= r->n_list) { pthread_mutex_unlock(&r->mu); return NULL; }
+        const int idx = r->next_parse++;
+        pthread_mutex_unlock(&r->mu);
+        const chunk_t *c = &r->chunks[r->list[idx]];
+        mtrh_batch *b = mtrh_parse_chunk(&r->files[c->file], c->begin, c->end, BATCH_READS, BATCH_BASES);
+        pthread_mutex_lock(&r->mu);
+        r->parsed[idx] = b; r->pstate[idx] = 1;
+        pthread_cond_broadcast(&r->cv_parse);
+        pthread_mutex_unlock(&r->mu);
+    }
+}
+
+/* ---- results ---------------------------------------------------------------------------------------------------------- */
+void mtrh_result_free(mtrh_result *x)
+{
+    if (!x) return;
+    mtrh_batch_free(x->batch);
+    free(x->counts); free(x->wire); free(x->chain_len); free(x->chain_idx); free(x->ops); free(x->ops_off); free(x->ends); free(x->after); free(x->fatal_msg);
+    free(x);
+}
+
+static void push_result(mtrh_run *r, mtrh_result *x)
+{
+    pthread_mutex_lock(&r->mu);
+    while (r->q_n == RESULT_QUEUE && !r->stopping) pthread_cond_wait(&r->cv_res, &r->mu);
+    if (r->stopping) { pthread_mutex_unlock(&r->mu); mtrh_result_free(x); return; }
+    r->queue[(r->q_head + r->q_n) % RESULT_QUEUE] = x; r->q_n++;
+    pthread_cond_broadcast(&r->cv_res);
+    pthread_mutex_unlock(&r->mu);
+}
+
+mtrh_result *mtrh_run_next(mtrh_run *r)
+{
+    pthread_mutex_lock(&r->mu);
+    while (r->q_n == 0 && !r->device_done) pthread_cond_wait(&r->cv_res, &r->mu);
+    mtrh_result *x = NULL;
+    if (r->q_n > 0) { x = r->queue[r->q_head]; r->q_head = (r->q_head + 1) % RESULT_QUEUE; r->q_n--; pthread_cond_broadcast(&r->cv_res); }
+    pthread_mutex_unlock(&r->mu);
+    return x;
+}
+
+static mtrh_result *result_new(int chunk, int file_idx, mtrh_batch *b)
+{
+    mtrh_result *x = (mtrh_result *)calloc(1, sizeof *x);
+    if (!x) { fprintf(stderr, "cannot allocate a result\n"); exit(EXIT_FAILURE); }
+    x->chunk = chunk; x->file_idx = file_idx; x->batch = b; x->n_report = b ? b->n : 0;
+    return x;
+}
+
+static void result_fail(mtrh_result *x, int n_report, const char *msg)
+{
+    x->fatal = 1; x->n_report = n_report;
+    free(x->fatal_msg); x->fatal_msg = strdup(msg ? msg : "device error");
+}
+
+static void *xmalloc(size_t n)
+{
+    void *p = malloc(n ? n : 1);
+    if (!p) { fprintf(stderr, "cannot allocate %zu bytes\n", n); exit(EXIT_FAILURE); }
+    return p;
+}
+
+/* -a: chain every read where the batch is resident, then ONE device call aligns all reported repeats of the batch */
+static void add_alignments(mtrh_run *r, mtr_ctx *ctx, mtrh_result *x)
+{
+    const mtrh_batch *b = x->batch;
+    const int n = x->n_report;
+    x->with_alignments = 1;
+    x->chain_len = (int32_t *)calloc((size_t)n + 1, sizeof(int32_t));
+    x->after = (uint8_t *)calloc((size_t)b->n * 2 + 2, 1);
+    int64_t total = 0;
+    for (int i = 0; i < n; i++) total += x->counts[i];
+    x->chain_idx = (int32_t *)xmalloc(sizeof(int32_t) * (size_t)(total + 1));
+    mtrh_rec *recs = (mtrh_rec *)xmalloc(sizeof(mtrh_rec) * (size_t)(total + 1));
+    int *tmp = (int *)xmalloc(sizeof(int) * (size_t)(total + 1));
+    const uint8_t *p = x->wire, *end = x->wire + x->wire_bytes;
+    int64_t nk = 0, base = 0;
+    int32_t *t_read = (int32_t *)xmalloc(sizeof(int32_t) * (size_t)(total + 1));
+    const mtrh_rec **t_rec = (const mtrh_rec **)xmalloc(sizeof(mtrh_rec *) * (size_t)(total + 1));
+    for (int i = 0; i < n; i++) {
+        const int c = x->counts[i];
+        for (int t = 0; t < c; t++) if (!mtrh_rec_next(&p, end, &recs[base + t])) { result_fail(x, 0, "internal error: malformed record table"); goto done; }
+        const int nc = c > 0 ? mtrh_chain(recs + base, c, tmp) : 0;
+        x->chain_len[i] = nc;
+        for (int t = 0; t < nc; t++) { x->chain_idx[nk] = tmp[t]; t_read[nk] = i; t_rec[nk] = &recs[base + tmp[t]]; nk++; }
+        base += c;
+    }
+    x->n_chain = nk;
+    for (int i = 0; i < b->n; i++) (void)r->eng.bases_after(ctx, i, x->after + 2 * (size_t)i);      /* zeros unless -B */
+    {
+        mtr_record *full = (mtr_record *)xmalloc(sizeof(mtr_record) * (size_t)(nk + 1));     /* the ABI takes mtr_record: header + unit are read */
+        for (int64_t k = 0; k < nk; k++) {
+            memcpy(&full[k], t_rec[k]->h, MTR_WIRE_HEADER_BYTES);
+            const int per = full[k].rep_period;
+            memcpy(full[k].unit, t_rec[k]->unit, (size_t)per); full[k].unit[per] = 0;
+        }
+        uint8_t *ops = NULL; int64_t *off = NULL; int32_t *ends = NULL;
+        const mtr_status st = r->eng.alignments(ctx, (int32_t)nk, t_read, full, &ops, &off, &ends);
+        free(full);
+        if (st != MTR_OK) { result_fail(x, 0, r->eng.last_error(ctx)); free(ops); free(off); free(ends); goto done; }
+        x->ops = ops; x->ops_off = off; x->ends = ends;
+    }
+done:
+    free(recs); free(tmp); free(t_read); free((void *)t_rec);
+}
+
+/* a batch whose kernels were started: wait, fetch the records in wire form (+ the alignments), hand the result on */
+static void finish_batch(mtrh_run *r, mtr_ctx *ctx, mtrh_result *x)
+{
+    const double t0 = now_s();
+    const mtrh_batch *b = x->batch;
+    mtr_status st = r->eng.wait(ctx);
+    int n_report = b->n;
+    if (st == MTR_ERR_DP_TOO_LARGE) {
+        /* like the reference (wrap_around_DP.c:96-99): everything before the failing read is reported, then the message */
+        int32_t ff = -1;
+        (void)r->eng.first_failed(ctx, &ff);
+        result_fail(x, ff > 0 ? ff : 0, r->eng.last_error(ctx));
+        n_report = x->n_report;
+    } else if (st != MTR_OK) { result_fail(x, 0, r->eng.last_error(ctx)); n_report = 0; }
+    x->counts = (int32_t *)calloc((size_t)n_report + 1, sizeof(int32_t));
+    if (n_report > 0) {
+        const uint8_t *blob = NULL; const int32_t *counts = NULL; int64_t bytes = 0, total = 0;
+        st = r->eng.fetch_packed(ctx, x->fatal ? n_report : -1, &blob, &bytes, &counts, &total);
+        if (st != MTR_OK) { result_fail(x, 0, r->eng.last_error(ctx)); n_report = 0; }
+        else {
+            memcpy(x->counts, counts, sizeof(int32_t) * (size_t)n_report);
+            x->wire = (uint8_t *)xmalloc((size_t)bytes + 8); x->wire_bytes = bytes;
+            if (bytes) memcpy(x->wire, blob, (size_t)bytes);
+        }
+    }
+    x->n_report = n_report;
+    mtr_kernel_time kt[2] = { { 0, 0 }, { 0, 0 } };
+    if (r->eng.kernel_times(ctx, kt, 2) == MTR_OK) x->t_kernel_ms = (double)kt[0].ms + (double)kt[1].ms;
+    int64_t cnt[MTR_N_COUNTERS];
+    if (r->eng.counters(ctx, cnt, MTR_N_COUNTERS) == MTR_OK) x->queries = cnt[8];
+    if (r->o.print_alignment && n_report > 0) add_alignments(r, ctx, x);
+    pthread_mutex_lock(&r->mu);
+    r->t_fetch += now_s() - t0; r->t_kernel += x->t_kernel_ms * 1e-3; r->queries += x->queries;
+    pthread_mutex_unlock(&r->mu);
+    push_result(r, x);
+}
+
+static void *device_main(void *arg)
+{
+    mtrh_run *r = (mtrh_run *)arg;
+    /* Two contexts = two device batches in flight.  The second one is created when a second batch shows up. */
+    mtr_ctx *ctxs[2] = { NULL, NULL };
+    mtr_file_state *fs = NULL;
+    int fs_file = -1;
+    mtrh_result *prev = NULL; mtr_ctx *prev_ctx = NULL;
+    int k = 0, dead = 0;
+    char *dead_msg = NULL;
+    int *file_ended = (int *)calloc((size_t)r->n_files + 1, sizeof(int));
+    for (int idx = 0; idx < r->n_list; idx++) {
+        double t0 = now_s();
+        pthread_mutex_lock(&r->mu);
+        while (!r->pstate[idx] && !r->stopping) pthread_cond_wait(&r->cv_parse, &r->mu);
+        mtrh_batch *b = r->parsed[idx]; r->parsed[idx] = NULL;
+        r->consumed = idx + 1;
+        pthread_cond_broadcast(&r->cv_parse);
+        const int stopping = r->stopping;
+        r->t_parse_wait += now_s() - t0;
+        pthread_mutex_unlock(&r->mu);
+        if (stopping) { mtrh_batch_free(b); break; }
+        const int cid = r->list[idx];
+        const chunk_t *c = &r->chunks[cid];
+        const int mine = c->owner == r->o.rank;
+        if (r->o.file_order && fs_file != c->file) {             /* the state is per file */
+            if (fs) r->eng.fs_destroy(fs);
+            fs = NULL; fs_file = c->file;
+            if (r->eng.fs_create(&fs) != MTR_OK) { dead = 1; dead_msg = strdup("fatal error: out of memory"); }
+        }
+        while (b) {
+            mtrh_batch *nx = b->next; b->next = NULL;
+            const int last = nx == NULL;
+            if (!mine) {                                         /* -B: reads another rank processes still shape the state */
+                if (fs && b->n > 0 && !file_ended[c->file]) (void)r->eng.fs_skip(fs, b->codes, b->offs, b->lens, b->n);
+                if (b->end != MTRH_END_NONE) file_ended[c->file] = 1;
+                mtrh_batch_free(b); b = nx;
+                continue;
+            }
+            mtrh_result *x = result_new(cid, c->file, b);
+            x->last_of_chunk = last;
+            if (dead) { x->n_report = 0; x->counts = (int32_t *)calloc(1, sizeof(int32_t)); result_fail(x, 0, dead_msg); }
+            if (dead || file_ended[c->file] || b->n == 0) {
+                /* nothing to run: an empty chunk (its status still travels), or input the reference never reads */
+                if (file_ended[c->file] && !dead) { x->n_report = 0; b->end = MTRH_END_NONE; }
+                if (!x->counts) x->counts = (int32_t *)calloc((size_t)x->n_report + 1, sizeof(int32_t));
+                if (b->n == 0) x->n_report = 0;
+                if (prev) { finish_batch(r, prev_ctx, prev); prev = NULL; }
+                if (b->end != MTRH_END_NONE) file_ended[c->file] = 1;
+                push_result(r, x);
+                b = nx;
+                continue;
+            }
+            t0 = now_s();
+            mtr_ctx **pc = &ctxs[k & 1];
+            mtr_status st = MTR_OK;
+            if (!*pc) {
+                st = r->eng.create(r->o.device, r->o.manhattan, r->o.min_match_ratio, pc);
+                if (st != MTR_OK) {
+                    char m[256];
+                    snprintf(m, sizeof m, "fatal error: no usable HIP device (mtr_create returned %d); this build has no CPU path", (int)st);
+                    dead = 1; dead_msg = strdup(m);
+                }
+            }
+            if (!dead) {
+                st = fs ? r->eng.upload_in_file(*pc, fs, b->codes, b->offs, b->lens, b->n)       /* uploads happen in file order */
+                        : r->eng.upload_packed(*pc, b->packed, b->n_words, b->woff, b->lens, b->n);
+                if (st == MTR_OK) st = r->eng.run_async(*pc);
+                if (st != MTR_OK) { dead = 1; dead_msg = strdup(r->eng.last_error(*pc)); }
+            }
+            if (!r->o.print_alignment && !r->o.file_order) { free(b->codes); b->codes = NULL; }   /* only -a rows and -B need the byte codes from here on */
+            free(b->packed); b->packed = NULL;
+            pthread_mutex_lock(&r->mu); r->t_submit += now_s() - t0; pthread_mutex_unlock(&r->mu);
+            if (prev) { finish_batch(r, prev_ctx, prev); prev = NULL; }       /* like the reference: everything before a failure is reported first */
+            if (dead) {
+                x->counts = (int32_t *)calloc(1, sizeof(int32_t));
+                result_fail(x, 0, dead_msg);
+                push_result(r, x);
+            } else {
+                if (b->end != MTRH_END_NONE) file_ended[c->file] = 1;
+                prev = x; prev_ctx = *pc; k++;
+            }
+            b = nx;
+        }
+    }
+    if (prev) finish_batch(r, prev_ctx, prev);
+    if (fs) r->eng.fs_destroy(fs);
+    for (int t = 0; t < 2; t++) if (ctxs[t]) r->eng.destroy(ctxs[t]);
+    free(file_ended); free(dead_msg);
+    pthread_mutex_lock(&r->mu);
+    r->device_done = 1;
+    pthread_cond_broadcast(&r->cv_res);
+    pthread_mutex_unlock(&r->mu);
+    return NULL;
+}
+
+/* ---- start / stop ------------------------------------------------------------------------------------------------------- */
+mtrh_run *mtrh_run_start(const mtrh_opts *o, const char *const *paths, int n_paths)
+{
+    mtrh_run *r = (mtrh_run *)calloc(1, sizeof *r);
+    if (!r) return NULL;
+    r->o = *o;
+    if (r->o.world < 1) { r->o.world = 1; r->o.rank = 0; }
+    char err[512];
+    if (mtrh_engine_load(&r->eng, o->engine_lib, err, sizeof err) != 0) { fprintf(stderr, "fatal error: %s\n", err); free(r); return NULL; }
+    r->n_files = n_paths; r->files = (mtrh_file *)calloc((size_t)n_paths, sizeof(mtrh_file));
+    for (int f = 0; f < n_paths; f++)
+        if (mtrh_file_open(&r->files[f], paths[f]) != 0) { for (int g = 0; g < f; g++) mtrh_file_close(&r->files[g]); free(r->files); free(r); return NULL; }
+    plan(r);
+    /* what this rank parses: its own chunks; with -B every chunk up to its last one (the state needs the reads before) */
+    r->list = (int *)malloc(sizeof(int) * ((size_t)r->n_chunks + 1));
+    int last_owned = -1;
+    for (int c = 0; c < r->n_chunks; c++) if (r->chunks[c].owner == r->o.rank) last_owned = c;
+    for (int c = 0; c <= last_owned; c++) if (r->chunks[c].owner == r->o.rank || r->o.file_order) r->list[r->n_list++] = c;
+    r->parsed = (mtrh_batch **)calloc((size_t)r->n_list + 1, sizeof(mtrh_batch *));
+    r->pstate = (int *)calloc((size_t)r->n_list + 1, sizeof(int));
+    pthread_mutex_init(&r->mu, NULL); pthread_cond_init(&r->cv_parse, NULL); pthread_cond_init(&r->cv_res, NULL);
+    int np = o->parse_threads;
+    if (np <= 0) { long nc = sysconf(_SC_NPROCESSORS_ONLN); np = nc >= 8 ? 4 : (nc >= 4 ? 2 : 1); }
+    if (np > 16) np = 16;
+    if (np > r->n_list) np = r->n_list > 0 ? r->n_list : 1;
+    r->n_parsers = np;
+    for (int t = 0; t < np; t++) pthread_create(&r->parsers[t], NULL, parser_main, r);
+    pthread_create(&r->device, NULL, device_main, r);
+    return r;
+}
+
+int mtrh_run_rank(const mtrh_run *r) { return r->o.rank; }
+int mtrh_run_n_chunks(const mtrh_run *r) { return r->n_chunks; }
+int mtrh_run_n_rounds(const mtrh_run *r) { return r->n_rounds; }
+int mtrh_run_owner(const mtrh_run *r, int chunk) { return chunk >= 0 && chunk < r->n_chunks ? r->chunks[chunk].owner : -1; }
+int mtrh_run_round_of(const mtrh_run *r, int chunk) { return chunk >= 0 && chunk < r->n_chunks ? r->chunks[chunk].round : -1; }
+
+void mtrh_run_timing(const mtrh_run *r, double *t_parse_wait, double *t_submit, double *t_fetch, double *t_kernel, long long *queries)
+{
+    if (t_parse_wait) *t_parse_wait = r->t_parse_wait;
+    if (t_submit) *t_submit = r->t_submit;
+    if (t_fetch) *t_fetch = r->t_fetch;
+    if (t_kernel) *t_kernel = r->t_kernel;
+    if (queries) *queries = r->queries;
+}
+
+void mtrh_run_stop(mtrh_run *r)
+{
+    if (!r) return;
+    pthread_mutex_lock(&r->mu);
+    r->stopping = 1;
+    pthread_cond_broadcast(&r->cv_parse); pthread_cond_broadcast(&r->cv_res);
+    pthread_mutex_unlock(&r->mu);
+    pthread_join(r->device, NULL);
+    for (int t = 0; t < r->n_parsers; t++) pthread_join(r->parsers[t], NULL);
+    for (int i = 0; i < r->q_n; i++) mtrh_result_free(r->queue[(r->q_head + i) % RESULT_QUEUE]);
+    for (int i = 0; i < r->n_list; i++) mtrh_batch_free(r->parsed[i]);
+    for (int f = 0; f < r->n_files; f++) mtrh_file_close(&r->files[f]);
+    mtrh_engine_unload(&r->eng);
+    pthread_mutex_destroy(&r->mu); pthread_cond_destroy(&r->cv_parse); pthread_cond_destroy(&r->cv_res);
+    free(r->files); free(r->chunks); free(r->list); free(r->parsed); free(r->pstate);
+    free(r);
+}

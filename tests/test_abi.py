@@ -20,12 +20,17 @@ def lib():
 
 
 def test_exports_every_declared_symbol(lib):
-    hdr = open(os.path.join(ROOT, "include", "mtr_hip.h")).read()
-    declared = set(re.findall(r"\b(mtr_[a-z_0-9]+)\s*\(", hdr))
-    assert declared >= set(mtr_amd.EXPORTS)
+    declared = set()
+    for h in ("mtr_hip.h", "mtr_hip_test.h"):
+        hdr = open(os.path.join(ROOT, "include", h)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)                       # comments mention functions too
+        inline = set(re.findall(r"static\s+inline\s+[a-z_0-9]+\s+(mtr_[a-z_0-9]+)\s*\(", hdr))
+        declared |= set(re.findall(r"^[a-z_0-9 \*]*?\b(mtr_[a-z_0-9]+)\s*\(", hdr, flags=re.M)) - inline
+    assert declared >= set(mtr_amd.EXPORTS), set(mtr_amd.EXPORTS) - declared
+    assert len(declared) >= 30
     for name in sorted(declared):
-        assert hasattr(lib, name), f"{name} declared in include/mtr_hip.h but not exported by libmtr_hip.so"
-    assert lib.mtr_abi_version() == 1
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported by libmtr_hip.so"
+    assert lib.mtr_abi_version() == 2
 
 
 def test_record_layout_matches_header():

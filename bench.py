@@ -2,27 +2,39 @@
 """bench.py — reads/s of the per-read hot path (handle_one_read) on MI355X, next to CPU mTR.
 
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --strong c4 ...               (strong scaling: ONE set of 100 000 config-4 reads split over the ranks)
 
-A "step" is one pass of the hot path (the per-read kernel mtr_k_reads: candidate ranges, unit search, wrap-around DPs,
-revision; mtr_run_resident) over one batch of synthetic reads that is already resident in HBM (2 bit/base).  Workload = the configuration BASELINE.json's
-metric is quoted on: 10 000 synthetic Nanopore-error reads of ~2 kb (unit 100 x 10 copies, 500-base flanks;
-mtr_amd.synth "headline2k") per GPU.  With N GPUs every rank holds its own 10 000 reads (weak scaling, no
-data-path collective); the step ends with the RCCL gather of the per-read record tables to rank 0 (the one
-exchange step of the path).  Rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path over one batch of synthetic reads that is already resident in HBM (2 bit/base):
+the per-read kernels (candidate ranges, unit search, wrap-around DPs, revision; mtr_run_resident) AND the hand-over at
+the boundary's lower edge — the record tables compacted on the device to the wire form and copied into pinned host
+memory (mtr_fetch_results_packed), i.e. the arguments of insert_an_alignment_into_set where the host's chaining takes
+them.  Workload = the configuration BASELINE.json's metric is quoted on: 10 000 synthetic Nanopore-error reads of ~2 kb
+(unit 100 x 10 copies, 500-base flanks; mtr_amd.synth "headline2k") per GPU.  Steps alternate between two contexts, so
+the fetch of step s overlaps the kernels of step s+1, as in the host pipeline (mtr_amd/host/pipeline.c).
 
-roofline: the only kernel is mtr_k_reads.  `achieved` = algorithmic HBM bytes of one launch (SURVEY.md §8d:
-B_alg = ceil(L/4) + 576 R + sum over the REFERENCE's DPs of ceil(cells/2), every DP counted as spilled because this
-build keeps all traceback cells in HBM-backed scratch; the DPs the kernel answers from its memo are part of the
-reference's work and are counted) / the kernel's average duration measured with HIP events on the launch stream.
-The path is NOT HBM-bound (row-serial integer recurrence: instruction issue + cross-lane scan latency): the
-VALU-side figure is reported in `roofline.valu` from the reference's DP cell updates.  `traffic` = HBM bytes/launch
-from the rocprofv3 PMC passes recorded in profiles/ (null until measured).
-cpu_baseline: rank 0, N=1 only — the reference mTR binary (oracle/_ref/mTR_ref, kind "reference") when it
-travelled with the repo, else the CPU oracle (kind "port"), on the first reads of the same workload, 1 core.
+  value          reads/s at the boundary (above);            value_kernel  the same steps without the fetch (round 1's figure)
+  value_cli      reads/s of the command line mtr_amd/host/mTR on a FASTA of the same reads, wall clock incl. process
+                 start, HIP initialisation, parsing, chaining and printing (N = 1 only; NOT resident inputs)
+With N GPUs (weak scaling) every rank holds its own 10 000 reads and the step ends with the ONE exchange of the path: the
+wire-form tables go device-to-device to rank 0 over RCCL (mtr_export_packed_device + gather).  --strong c4: BASELINE
+config 4 — one set of 100 000 mixed-unit reads, contiguous blocks balanced by sum of lengths; rank 0 checks the sha256 of
+the gathered stream against the known answer of the CPU oracle (tests/golden/c4_100k_wire.json) and reports ranks_seen.
+
+roofline: the dominant kernel is mtr_k_reads.  `achieved` = algorithmic HBM bytes of one launch (B_alg =
+ceil(L/4) + 576 R + sum over the REFERENCE's DPs of ceil(cells/2), every DP counted as spilled; the DPs the kernel answers
+from its memo are part of the reference's work and are counted) / the kernel's average duration measured with HIP events
+on the launch stream.  The path is NOT HBM-bound (row-serial integer recurrence: instruction issue + cross-lane latency):
+`valu` prices the reference's DP cell updates against the VALU peak, `issue` is the measured VALU issue utilisation.
+`traffic` (HBM bytes per launch, FETCH_SIZE x 2 + WRITE_SIZE as the gfx950 guide prescribes) and `issue` come from the
+rocprofv3 PMC passes committed under profiles/ (profiles/pmc_latest.json); they are reported only while the kernel
+sources are the ones that were profiled (sha of mtr_amd/csrc), else null.
+cpu_baseline: rank 0, N = 1 only — the reference mTR binary (oracle/_ref/mTR_ref, kind "reference") when it travelled
+with the repo, else the CPU oracle (kind "port"), on the first reads of the same workload, 1 core (and all cores).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -40,6 +52,29 @@ WORKLOAD = "headline2k"
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz = 78.6 T lane-ops/s
 OPS_PER_CELL = 7                 # ~7 integer ops per DP cell update
+
+
+def kernel_sources_sha():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mtr_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".inc", ".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profiled_counters():
+    """(traffic bytes/launch with the FETCH x 2 correction, VALU issue utilisation, tag) from profiles/pmc_latest.json, or
+    Nones when the kernel sources changed since that profile was taken."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
+            p = json.load(fh)
+    except Exception:
+        return None, None, "no profile"
+    if p.get("kernel_src_sha") != kernel_sources_sha():
+        return None, None, f"stale: profiled at kernel sources {p.get('kernel_src_sha')}"
+    return p.get("k2_hbm_bytes_per_launch_fetch_x2"), p.get("valu_issue_utilisation"), p.get("tag", "")
 
 
 def cpu_baseline(reads, n_sample):
@@ -62,7 +97,6 @@ def cpu_baseline(reads, n_sample):
         one = {"value": len(sample) / dt, "unit": "reads/s", "cores": 1, "kind": kind,
                "sample": f"first {len(sample)} reads of the workload, one process, {dt:.1f} s"}
         # the same binary on every host core of this box's share: one process per core, each on its own reads
-        # (SURVEY.md 8d asks for both figures); same number of reads per process as above, so it takes as long
         cores = max(1, min(16, len(os.sched_getaffinity(0))))      # 16 = the CPU share of a one-GPU box on this pool
         if cores > 1:
             per = max(1, min(len(sample), len(reads) // cores))
@@ -81,14 +115,30 @@ def cpu_baseline(reads, n_sample):
     return one
 
 
-def measured_traffic():
-    """HBM bytes per K2 launch from the committed rocprofv3 PMC summary (profiles/pmc_latest.json), or None."""
-    p = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    try:
-        with open(p) as fh:
-            return float(json.load(fh)["k2_hbm_bytes_per_launch"])
-    except Exception:
-        return None
+def cli_rate(reads, n):
+    """wall clock of the command line on a FASTA of the first n reads (page cache warm), best of 2"""
+    from mtr_amd import synth
+
+    exe = os.path.join(ROOT, "mtr_amd", "host", "mTR")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(exe), "mTR"], check=True)
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, "reads.fa")
+        synth.write_fasta(fa, [(str(i), reads[i % len(reads)]) for i in range(n)])
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            p = subprocess.run([exe, fa], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            dt = time.perf_counter() - t0
+            if p.returncode != 0:
+                return {"error": p.stderr.decode()[-200:]}
+            best = dt if best is None else min(best, dt)
+    return {"reads": n, "seconds": best, "reads_per_s": n / best}
+
+
+def shard_bounds(lens, world):
+    from mtr_amd.dist import shard_bounds as sb
+    return sb(lens, world)
 
 
 def main():
@@ -97,10 +147,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=READS_PER_GPU, help="reads per GPU (default = the headline workload)")
+    ap.add_argument("--strong", default=None, choices=["c4"], help="strong scaling: one fixed read set split over the ranks")
+    ap.add_argument("--strong-reads", type=int, default=100000)
     ap.add_argument("--cpu-sample", type=int, default=2000, help="reads timed on the CPU baseline (0 = skip); 2000 reads ~ 15 s on one core")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--rehearse-exchange", action="store_true", help="development aid, 1 GPU: run the per-step record export of the "
-                    "multi-GPU path (compaction kernel + a device copy in place of the RCCL gather) to see what it costs the pipeline")
+    ap.add_argument("--no-cli", action="store_true")
     a = ap.parse_args()
 
     import torch
@@ -108,7 +159,6 @@ def main():
 
     import mtr_amd
     from mtr_amd import synth
-    from mtr_amd.dist import RECORD_BYTES, gather_records
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -121,37 +171,56 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    # every rank owns its own block of reads (weak scaling): same distribution, different seed
-    reads = [c for _, c in synth.make_reads(WORKLOAD, a.reads, seed=2 + rank)]
-    # Two contexts (own stream, own result and scratch buffers) hold the same resident batch: consecutive steps
-    # alternate between them, so the kernels of step s+1 are enqueued while the last wavefronts of step s are
-    # still finishing (a read is one wavefront's serial chain, the slowest read of a batch takes ~3x the mean).
-    # Every step still does all of its work; only the barrier between steps is gone, as in a real multi-batch run.
-    # batches in flight: 2 on one GPU (3 and 4 measured: no gain).  With an exchange step (N > 1) one more, so that the next
-    # kernel is already enqueued while the host waits for the gather of the previous step, whose RCCL kernels may only get
-    # their wave slots when the resident kernel's first waves retire
+    if a.strong:
+        # one data set for the whole job: every rank generates it (seeded) and keeps its contiguous block
+        allr = [c for _, c in synth.make_reads(a.strong, a.strong_reads, 4)]
+        b = shard_bounds([len(r) for r in allr], world)
+        reads = allr[b[rank]: b[rank + 1]]
+        n_job = len(allr)
+        del allr
+    else:
+        # every rank owns its own block of reads (weak scaling): same distribution, different seed
+        reads = [c for _, c in synth.make_reads(WORKLOAD, a.reads, seed=2 + rank)]
+        n_job = len(reads) * world
+    # Two contexts (own stream, own result and scratch buffers) hold the same resident batch: consecutive steps alternate
+    # between them, so the kernels of step s+1 are enqueued while step s is fetched (and while its last wavefronts finish:
+    # a read is one wavefront's serial chain).  Every step does all of its work.  With an exchange step (N > 1) one more
+    # context, so that the next kernel is already enqueued while the host waits for the gather of the previous step.
     NCTX = int(os.environ.get("MTR_BENCH_CONTEXTS", "2" if world == 1 else "3"))
     engs = [mtr_amd.Engine(device=local_rank) for _ in range(NCTX)]
     for e in engs:
         e.upload(reads)                                 # inputs resident in HBM before the timed region
     eng = engs[0]
+    wire_buf = [None] * NCTX
+    gathered = {}
 
-    rec_buf = [None] * NCTX
+    def exchange(s, keep=False):
+        """the path's one exchange: wire-form tables device-to-device to rank 0"""
+        e = engs[s % NCTX]
+        wb = wire_buf[s % NCTX]
+        need = max(1 << 20, 700 * max(1, e.counters()["records"]))
+        if wb is None or wb.numel() < need:
+            wb = wire_buf[s % NCTX] = torch.empty(need * 5 // 4, dtype=torch.uint8, device="cuda")
+        counts, total, nbytes = e.export_packed_device(wb.data_ptr(), wb.numel())
+        sizes = torch.tensor([nbytes, total, len(counts)], dtype=torch.int64, device="cuda")
+        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+        dist.all_gather(all_sizes, sizes)
+        width = max(int(x[0]) for x in all_sizes)
+        pad = wb[: max(width, 1)]
+        out = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+        dist.gather(pad, out, dst=0)
+        if rank == 0 and keep:
+            gathered["blobs"] = [out[r][: int(all_sizes[r][0])].cpu().numpy().tobytes() for r in range(world)]
+            gathered["records"] = [int(x[1]) for x in all_sizes]
+            gathered["reads"] = [int(x[2]) for x in all_sizes]
 
-    def finish(s):
+    def finish(s, fetch=True, keep=False):
         e = engs[s % NCTX]
         e.wait()
-        if world > 1 or a.rehearse_exchange:
-            # exchange step: gather the per-read record tables to rank 0 over RCCL
-            total = e.counters()["records"]
-            rb = rec_buf[s % NCTX]
-            if rb is None or rb.numel() < total * RECORD_BYTES:
-                rb = rec_buf[s % NCTX] = torch.empty(max(total, 1) * RECORD_BYTES * 5 // 4, dtype=torch.uint8, device="cuda")
-            counts, tot = e.export_records_device(rb.data_ptr(), rb.numel() // RECORD_BYTES)
-            if world > 1:
-                gather_records(rb[: tot * RECORD_BYTES], torch.from_numpy(counts).cuda(), dst=0)
-            else:
-                rb[: tot * RECORD_BYTES].clone(); torch.from_numpy(counts).cuda(); torch.cuda.current_stream().synchronize()
+        if world > 1:
+            exchange(s, keep)
+        elif fetch:
+            e.fetch_packed_nocopy()                     # wire form -> pinned host memory of the context
         return e.kernel_times_ms()
 
     def sync():
@@ -159,34 +228,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    sync_k1, sync_k2 = [], []
+    def timed(steps, fetch=True):
+        k2 = []
+        sync()
+        t0 = time.perf_counter()
+        depth = NCTX - 1                                # steps enqueued ahead of the one being finished
+        for s in range(min(depth, steps)):
+            engs[s % NCTX].run_async()
+        for s in range(steps):
+            if s + depth < steps:
+                engs[(s + depth) % NCTX].run_async()
+            k2.append(finish(s, fetch, keep=(s == steps - 1))["k2_units"])
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, k2
+
+    sync_k2 = []
     for w in range(a.warmup):                           # warm-up steps run one at a time (un-overlapped kernel times)
         engs[w % NCTX].run_async()
-        kt = finish(w)
-        sync_k1.append(kt["k1_ranges"]); sync_k2.append(kt["k2_units"])
-    k2_ms, k1_ms = [], []
-    sync()
-    t0 = time.perf_counter()
-    depth = NCTX - 1                                    # steps enqueued ahead of the one being finished
-    for s in range(min(depth, a.steps)):
-        engs[s % NCTX].run_async()
-    for s in range(a.steps):
-        if s + depth < a.steps:
-            engs[(s + depth) % NCTX].run_async()
-        kt = finish(s)
-        k1_ms.append(kt["k1_ranges"]); k2_ms.append(kt["k2_units"])
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        sync_k2.append(finish(w)["k2_units"])
+    dt, k2_ms = timed(a.steps, fetch=True)
+    dt_kernel = None
+    if world == 1:
+        dt_kernel, _ = timed(a.steps, fetch=False)      # round 1's figure: the kernels alone, results left on the device
 
     if rank == 0:
         cnt = eng.counters()
         n_local = len(reads)
-        total_reads = n_local * world * a.steps
-        value = total_reads / dt
+        value = n_job * a.steps / dt
         # algorithmic bytes of one launch (this rank's batch): the reference's DP cells = computed + answered from the memo
         sumL4 = sum((len(r) + 3) // 4 for r in reads)
         cells = cnt["dp_cells"] + cnt["revise_dp_cells"] + cnt["memo_cells"]
@@ -194,6 +267,14 @@ def main():
         k2_avg_s = float(np.mean(k2_ms)) / 1e3
         achieved_gbs = b_alg / k2_avg_s / 1e9
         valu_ops = cells * OPS_PER_CELL / k2_avg_s
+        traffic, issue, prof_tag = profiled_counters()
+        wire_bytes = len(eng.fetch_packed()[0]) if world == 1 else None
+        if a.strong:
+            workload = (f"{a.strong}: ONE set of {n_job} synthetic Nanopore reads (unit 50-200 x 10 copies, L ~ 2 kb), contiguous blocks balanced "
+                        f"by sum of lengths over {world} GPU(s)")
+        else:
+            workload = (f"{WORKLOAD}: {n_local} synthetic Nanopore reads per GPU, unit 100 x 10 copies, 500-base flanks, "
+                        f"mean L {np.mean([len(r) for r in reads]):.0f}, error profile sub 1.6/ins 9.0/del 3.8 %")
         out = {
             "metric": "reads/sec, 2 kb Nanopore synthetic",
             "value": value,
@@ -203,26 +284,61 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if a.strong else "weak",
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": f"{WORKLOAD}: {n_local} synthetic Nanopore reads per GPU, unit 100 x 10 copies, 500-base flanks, "
-                                   f"mean L {np.mean([len(r) for r in reads]):.0f}, error profile sub 1.6/ins 9.0/del 3.8 %",
-                       "reads_per_gpu": n_local, "parallelism": f"reads sharded over {world} GPU(s), gather to rank 0"},
-            "ms_per_read": dt / a.steps * 1e3 / n_local,
+            "config": {"workload": workload, "reads_per_gpu": n_local,
+                       "parallelism": f"reads sharded over {world} GPU(s), wire-form record tables gathered to rank 0" if world > 1
+                                      else "1 GPU, record tables fetched to pinned host memory in wire form"},
+            "value_definition": "steps end with the record tables in host memory (wire form, mtr_fetch_results_packed)" if world == 1
+                                else "steps end with the record tables of every rank gathered on rank 0's GPU (RCCL)",
+            "ms_per_read": dt / a.steps * 1e3 / max(n_job, 1),
             "kernels_ms": {"mtr_k_reads": float(np.mean(k2_ms)),
                            "note": "HIP-event durations over the timed region; consecutive steps overlap on the GPU, so a launch shares the chip with its neighbour"},
             "kernels_ms_alone": {"mtr_k_reads": float(np.mean(sync_k2)) if sync_k2 else None},
             "work_per_launch": {k: cnt[k] for k in ("dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_dp_cells", "memo_hits", "memo_cells",
                                                     "kmer_tables", "tables_skipped", "kmer_lookups", "ranges_executed", "records", "traceback_steps")},
             "roofline": {"bound": "hbm", "kernel": "mtr_k_reads", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(),
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": prof_tag,
                          "algorithmic_bytes_per_launch": b_alg,
                          "valu": {"achieved_lane_ops_per_s": valu_ops, "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
                                   "frac": valu_ops / VALU_PEAK_LANE_OPS, "cells_per_launch": cells, "ops_per_cell": OPS_PER_CELL},
-                         "note": "not HBM-bound: row-serial integer max-plus recurrence (instruction issue + cross-lane scan latency); cells = the reference's DP cells, of which memo_cells were answered without a DP"},
+                         "issue": issue,
+                         "note": "not HBM-bound: row-serial integer max-plus recurrence (instruction issue + cross-lane scan latency); cells = the reference's DP "
+                                 "cells, of which memo_cells were answered without a DP; issue = VALU issue utilisation (SQ_INSTS_VALU x 2 cycles / SIMD-cycles of the launch)"},
         }
+        if world == 1:
+            out["value_kernel"] = n_job * a.steps / dt_kernel
+            out["boundary"] = {"wire_bytes_per_step": wire_bytes, "record_struct_bytes_per_step": 2560 * cnt["records"],
+                               "fetch_cost_ms_per_step": (dt - dt_kernel) / a.steps * 1e3}
+        if a.strong and "blobs" in gathered:
+            h = hashlib.sha256()
+            for bl in gathered["blobs"]:
+                h.update(bl)
+            known = None
+            try:
+                with open(os.path.join(ROOT, "tests", "golden", f"c4_{'100k' if n_job == 100000 else n_job}_wire.json")) as fh:
+                    known = json.load(fh)
+            except Exception:
+                pass
+            out["strong"] = {"ranks_seen": sum(1 for n in gathered["reads"] if n > 0), "reads_per_rank": gathered["reads"],
+                             "records": sum(gathered["records"]), "sha256": h.hexdigest(),
+                             "matches_oracle": (known is not None and known["sha256"] == h.hexdigest() and known["records"] == sum(gathered["records"]))
+                                               if known else None,
+                             "known_answer": "tests/golden/c4_100k_wire.json (CPU oracle)" if known else None}
+        elif a.strong and world == 1:
+            data, counts = eng.fetch_packed()
+            known = None
+            try:
+                with open(os.path.join(ROOT, "tests", "golden", f"c4_{'100k' if n_job == 100000 else n_job}_wire.json")) as fh:
+                    known = json.load(fh)
+            except Exception:
+                pass
+            hx = hashlib.sha256(data).hexdigest()
+            out["strong"] = {"ranks_seen": 1, "reads_per_rank": [n_local], "records": int(counts.sum()), "sha256": hx,
+                             "matches_oracle": (known["sha256"] == hx) if known else None,
+                             "known_answer": "tests/golden/c4_100k_wire.json (CPU oracle)" if known else None}
         if world == 1 and not a.no_latency:
             lat = []
             e2 = mtr_amd.Engine(device=local_rank)
@@ -232,11 +348,23 @@ def main():
                 lat.append((time.perf_counter() - t1) * 1e3)
             e2.close()
             out["latency_ms_per_read_p50"] = float(np.median(lat[1:]))
-        if world == 1 and a.cpu_sample > 0:
+        if world == 1 and not a.no_cli and not a.strong:
+            for e in engs:                              # the command line brings its own contexts: free this process's memory first
+                e.close()
+            engs.clear()
+            torch.cuda.empty_cache()
+            c1 = cli_rate(reads, len(reads))
+            c10 = cli_rate(reads, 10 * len(reads))
+            out["value_cli"] = c10.get("reads_per_s")
+            out["cli"] = {"note": "mtr_amd/host/mTR <fasta> > /dev/null, wall clock incl. process start and HIP initialisation; best of 2",
+                          "one_batch": c1, "ten_batches": c10}
+        if world == 1 and a.cpu_sample > 0 and not a.strong:
             out["cpu_baseline"] = cpu_baseline(reads, a.cpu_sample)
             out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"]
             if "all_cores" in out["cpu_baseline"]:
                 out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline"]["all_cores"]["value"]
+            if out.get("value_cli"):
+                out["speedup_cli_vs_cpu_1core"] = out["value_cli"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     for e in engs:
         e.close()

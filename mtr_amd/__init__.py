@@ -304,6 +304,14 @@ class Engine:
         data = C.string_at(blob, nbytes.value) if nbytes.value else b""
         return data, counts
 
+    def fetch_packed_nocopy(self):
+        """mtr_fetch_results_packed, leaving the wire form where the boundary hands it over (the context's pinned host
+        buffer): returns (bytes, records)"""
+        blob, cnts = C.c_void_p(), C.c_void_p()
+        nbytes, total = C.c_int64(), C.c_int64()
+        self._check(self.lib.mtr_fetch_results_packed(self.h, -1, C.byref(blob), C.byref(nbytes), C.byref(cnts), C.byref(total)), "mtr_fetch_results_packed")
+        return int(nbytes.value), int(total.value)
+
     def fetch_via_wire(self) -> List[List[Record]]:
         """the records of the last run through the wire form and mtr_unpack_records (must equal fetch())"""
         data, counts = self.fetch_packed()

@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
-"""Condense one profiles/collect.sh run (gpurun_out/prof_<tag>/) into gpurun_out/prof_<tag>/summary.json.
+"""Condense one profiles/collect_all.sh run (gpurun_out/prof_<tag>/) into gpurun_out/prof_<tag>/summary.json.
 
-Copy summary.json to profiles/<round>_<tag>_summary.json (and to profiles/pmc_latest.json, which bench.py reads for
-roofline.traffic) and the kernel_stats csv next to it.
+Copy summary.json to profiles/<round>_<tag>_summary.json and to profiles/pmc_latest.json (bench.py reads roofline.traffic and
+roofline.issue from the latter, and only while the kernel sources still have the sha recorded here), and the kernel_stats
+csv next to it.
 FETCH_SIZE / WRITE_SIZE: rocprofv3 reports KiB -> bytes = value * 1024.  gfx950 correction (MI355X_MICROARCH.md, HBM):
-FETCH_SIZE reports 1/2 of the bytes of wide coalesced 16 B/lane streaming reads; this kernel's reads are byte- and
-dword-granular (traceback windows, k-mer tables, packed words) = an uncalibrated pattern, so both the raw and the
-2x figure are given; `traffic` uses the raw one.  WRITE_SIZE is exact for streaming stores.
+FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads -> `k2_hbm_bytes_per_launch_fetch_x2` doubles the
+read side as the guide prescribes; the raw sum is kept beside it.  WRITE_SIZE is exact for streaming stores.
+VALU issue utilisation = SQ_INSTS_VALU x 2 cycles (a wave64 VALU instruction occupies a SIMD-32 for two passes)
+/ (SIMDs x launch duration x clock); lanes doing reference work = algorithmic cell-ops / (SQ_INSTS_VALU x 64).
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DOMINANT = "mtr_k"          # every kernel of the library starts with this
 
 
 def counter_rows(d):
@@ -23,45 +29,78 @@ def counter_rows(d):
     return rows
 
 
-def per_kernel(rows, counter):
+def per_kernel(rows):
+    """{kernel: {counter: mean per launch}}"""
     acc = {}
     for r in rows:
-        if r.get("Counter_Name") != counter:
+        k = r.get("Kernel_Name", "?").split("(")[0].replace("void ", "")
+        if DOMINANT not in k:
             continue
-        k = r.get("Kernel_Name", "?")
-        did = r.get("Dispatch_Id", "0")
-        acc.setdefault(k, {}).setdefault(did, 0.0)
-        acc[k][did] += float(r["Counter_Value"])
-    return {k: {"launches": len(v), "bytes_per_launch": sum(v.values()) * 1024.0 / len(v)} for k, v in acc.items()}
+        a = acc.setdefault(k, {}).setdefault(r["Counter_Name"], {})
+        a[r["Dispatch_Id"]] = a.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    return {k: {c: sum(v.values()) / len(v) for c, v in cs.items()} | {"_launches": max(len(v) for v in cs.values())} for k, cs in acc.items()}
+
+
+def kernel_sources_sha():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mtr_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".inc", ".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
     out, tag = sys.argv[1], sys.argv[2]
-    s = {"tag": tag, "command": "bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-latency under rocprofv3 (three separate runs)"}
+    s = {"tag": tag, "kernel_src_sha": kernel_sources_sha(),
+         "command": "bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-latency --no-cli under rocprofv3 (one pass per counter group)"}
     stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    dur_ms = {}
     if stats:
         with open(stats[0]) as fh:
             s["kernel_stats"] = [dict(r) for r in csv.DictReader(fh)]
+        for r in s["kernel_stats"]:
+            if DOMINANT in r.get("Name", ""):
+                dur_ms[r["Name"].split("(")[0].replace("void ", "")] = float(r["AverageNs"]) / 1e6
     try:
         with open(os.path.join(out, "bench_trace.json")) as fh:
             b = json.loads(fh.read().strip().splitlines()[-1])
         s["bench_under_rocprof"] = {"value": b["value"], "ms_per_step": b["ms_per_step"], "kernels_ms": b["kernels_ms"],
-                                    "kernels_ms_alone": b.get("kernels_ms_alone"), "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"]}
+                                    "kernels_ms_alone": b.get("kernels_ms_alone"), "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"],
+                                    "cells_per_launch": b["roofline"]["valu"]["cells_per_launch"]}
     except Exception as e:      # noqa: BLE001
         s["bench_under_rocprof"] = f"unreadable: {e}"
-    f = per_kernel(counter_rows(os.path.join(out, "fetch")), "FETCH_SIZE")
-    w = per_kernel(counter_rows(os.path.join(out, "write")), "WRITE_SIZE")
-    s["fetch"] = f
-    s["write"] = w
-    for k in f:
-        if "mtr_k_reads" in k and k in w:
-            s["k2_fetch_bytes_per_launch"] = f[k]["bytes_per_launch"]
-            s["k2_write_bytes_per_launch"] = w[k]["bytes_per_launch"]
-            s["k2_hbm_bytes_per_launch"] = f[k]["bytes_per_launch"] + w[k]["bytes_per_launch"]
-            s["k2_hbm_bytes_per_launch_fetch_x2"] = 2 * f[k]["bytes_per_launch"] + w[k]["bytes_per_launch"]
+    groups = {g: per_kernel(counter_rows(os.path.join(out, g))) for g in ("fetch", "write", "sq1", "sq2", "lds")}
+    s["counters_per_launch"] = groups
+    dom = max(dur_ms, key=dur_ms.get) if dur_ms else None
+    s["dominant_kernel"] = dom
+    if dom:
+        g = lambda grp, c: groups.get(grp, {}).get(dom, {}).get(c)      # noqa: E731
+        f, w = g("fetch", "FETCH_SIZE"), g("write", "WRITE_SIZE")
+        if f is not None and w is not None:
+            s["k2_fetch_bytes_per_launch"] = f * 1024.0
+            s["k2_write_bytes_per_launch"] = w * 1024.0
+            s["k2_hbm_bytes_per_launch"] = (f + w) * 1024.0
+            s["k2_hbm_bytes_per_launch_fetch_x2"] = (2 * f + w) * 1024.0
+        valu, salu = g("sq2", "SQ_INSTS_VALU"), g("sq2", "SQ_INSTS_SALU")
+        if valu:
+            simds, clock = 1024, 2.4e9
+            s["valu_issue_utilisation"] = valu * 2.0 / (simds * dur_ms[dom] * 1e-3 * clock)
+            s["insts_valu_plus_salu"] = valu + (salu or 0.0)
+            cells = s["bench_under_rocprof"].get("cells_per_launch") if isinstance(s["bench_under_rocprof"], dict) else None
+            if cells:
+                s["lanes_doing_reference_work"] = cells * 7.0 / (valu * 64.0)
+                s["cells_per_instruction"] = cells / (valu + (salu or 0.0))
+        bc, ia = g("lds", "SQ_LDS_BANK_CONFLICT"), g("lds", "SQ_LDS_IDX_ACTIVE")
+        if bc is not None and ia:
+            s["lds_bank_conflict_share_of_lds_cycles"] = bc / ia
+            wc = g("sq1", "SQ_WAVE_CYCLES")
+            if wc:
+                s["lds_array_busy_share_of_wave_cycles"] = ia / (4.0 * wc)
     with open(os.path.join(out, "summary.json"), "w") as fh:
         json.dump(s, fh, indent=1)
-    print(json.dumps({k: v for k, v in s.items() if k.startswith("k2_")}))
+    print(json.dumps({k: v for k, v in s.items() if k not in ("kernel_stats", "counters_per_launch")}))
 
 
 if __name__ == "__main__":

@@ -74,7 +74,7 @@ def test_search_stage_matches_reference_G2(name):
     assert n > 20
 
 
-@pytest.mark.parametrize("name", ["3_5", "synth_2k", "synth_c2", "10_50"])
+@pytest.mark.parametrize("name", ["synth_2k", "synth_c2", "10_50", "20_50"])
 def test_polish_and_revision_stages_match_reference_G3p_G3r(name):
     ev = traced_run(name, (1 << 4) | (1 << 5))
     cap = gu.capture_by_read(name, "default")

@@ -27,6 +27,7 @@
 #include "mtr_common.h"
 #include "k1_ranges.hip.inc"
 #include "k2_units.hip.inc"
+#include "k3_staged.hip.inc"
 
 static_assert(sizeof(DevRecord) == sizeof(mtr_record), "device and ABI record layouts must agree");
 static_assert(MTR_N_COUNTERS == CNT_N, "counter count");
@@ -75,7 +76,12 @@ struct mtr_ctx {
     int32_t *d_trace = nullptr; unsigned *d_trace_n = nullptr; int trace_cap = 0;
     // range-parallel mode (small batches): work items = (read, range), parked candidate records
     int32_t *d_item_read = nullptr, *d_item_idx = nullptr, *d_cand_flag = nullptr; int64_t *d_item_off = nullptr; DevRecord *d_cand = nullptr;
-    int64_t item_cap = 0; bool last_split = false;
+    int64_t item_cap = 0; bool last_split = false, last_staged = false;
+    // staged mode (k3_staged.hip.inc): fixed-capacity buffers of one batch
+    uint8_t *d_st_arena = nullptr, *d_st_codes = nullptr; int64_t *d_st_kc = nullptr; StDpItem *d_st_dp = nullptr;
+    unsigned *d_st_bincnt = nullptr; int32_t *d_st_dpbin = nullptr, *d_st_dprank = nullptr, *d_st_binstart = nullptr, *d_st_sorted = nullptr, *d_st_classwave = nullptr;
+    DevRecord *d_st_cand = nullptr; int32_t *d_st_flag = nullptr; unsigned long long *d_st_scalars = nullptr;
+    int32_t *d_st_wv = nullptr, *d_st_res = nullptr; int4 *d_st_items = nullptr;
     std::vector<std::pair<void *, size_t>> caps;       // (address of the pointer member, bytes allocated)
     // reads that found more records than their max_rec slots are run again with room for all of them (resolve_overflow)
     std::vector<int32_t> ovf_reads; int ovf_cap = 0;
@@ -237,6 +243,8 @@ static void release_batch_buffers(mtr_ctx *ctx)
     dfree(ctx->d_ovf_records); dfree(ctx->d_rec_base); dfree(ctx->d_ovf_order); dfree(ctx->d_src);
     dfree(ctx->d_item_read); dfree(ctx->d_item_idx); dfree(ctx->d_cand_flag); dfree(ctx->d_item_off); dfree(ctx->d_cand); ctx->item_cap = 0;
     dfree(ctx->d_tail); dfree(ctx->d_tail_off);
+    dfree(ctx->d_st_arena); dfree(ctx->d_st_codes); dfree(ctx->d_st_kc); dfree(ctx->d_st_dp); dfree(ctx->d_st_bincnt); dfree(ctx->d_st_dpbin); dfree(ctx->d_st_dprank);
+    dfree(ctx->d_st_binstart); dfree(ctx->d_st_sorted); dfree(ctx->d_st_classwave); dfree(ctx->d_st_cand); dfree(ctx->d_st_flag); dfree(ctx->d_st_scalars); dfree(ctx->d_st_wv); dfree(ctx->d_st_res); dfree(ctx->d_st_items);
     dfree(ctx->d_wire_bytes); dfree(ctx->d_wire_off); dfree(ctx->d_wire);
     dfree(ctx->d_al_i32); dfree(ctx->d_al_len); dfree(ctx->d_al_ends); dfree(ctx->d_al_units); dfree(ctx->d_al_ops); dfree(ctx->d_al_off);
     dfree(ctx->d_t_i32); dfree(ctx->d_t_out); dfree(ctx->d_t_units);
@@ -457,6 +465,7 @@ static mtr_status check_status(mtr_ctx *ctx)
     case DEV_ERR_RANGE_OVERFLOW: ctx->err = "a read produced more candidate ranges than L/2+64"; return MTR_ERR_OVERFLOW;
     case DEV_ERR_RECORD_OVERFLOW: ctx->err = "a read produced more records than the per-read capacity"; return MTR_ERR_OVERFLOW;
     case DEV_ERR_DP_TOO_LARGE: ctx->err = "You need to increse the value of WrapDPsize. (a DP exceeded the reference's 2e8 cells)"; return MTR_ERR_DP_TOO_LARGE;
+    case DEV_ERR_STAGED_OVERFLOW: ctx->err = "a buffer of the staged mode was too small for this batch"; return MTR_ERR_OVERFLOW;
     default: ctx->err = "internal device error " + std::to_string(st); return MTR_ERR_HIP;
     }
 }
@@ -660,6 +669,130 @@ static mtr_status launch_split(mtr_ctx *ctx)
     return MTR_OK;
 }
 
+// Staged mode (k3_staged.hip.inc): ranges of every read, then every (read, range) through phase 1, then ALL two-parameter DPs
+// of the batch one per lane, then tracebacks + selection + revision per range, then the replay of the sequential loop.
+// One stream, no host round trip; every buffer has a capacity fixed here, and a batch that outgrows one is run again
+// by the per-read kernel (mtr_wait).  MTR_STAGED=0/1 forces it off/on.
+static int staged_lane_umax()
+{   // units up to this length are aligned one DP per lane (mtr_k_dp2_lanes), longer ones one wavefront per DP (MTR_STAGED_LANE_UMAX)
+    const char *e = getenv("MTR_STAGED_LANE_UMAX");
+    const int v = e ? atoi(e) : 0;
+    return v < 0 ? 0 : (v > ST_UMAX ? ST_UMAX : v);
+}
+static bool use_staged(const mtr_ctx *ctx)
+{
+    const char *e = getenv("MTR_STAGED");
+    if (e) return atoi(e) != 0;
+    if (getenv("MTR_SPLIT")) return false;                 // an explicit choice between the two older modes
+    // [measured, host call on one resident batch of 2 kb reads] 1 read: 3.2 ms (range-parallel mode 9 ms, per-read kernel
+    // 19 ms); 64: 12 / 16 / 30 ms; 2 000: 30 / 35 / 39 ms; 10 000: 87 / 98 / 79 ms -> up to MTR_STAGED_MAX_READS (6 000)
+    // reads.  Batches of long reads keep the range-parallel mode: its ranges run through all phases without a barrier
+    // between them (16 reads of 42 kb: 180 ms against 236 ms), except a single read (141 against 176 ms).
+    const char *m = getenv("MTR_STAGED_MAX_READS");
+    const long max_reads = m ? atol(m) : 6000;
+    if (ctx->n_reads > max_reads) return false;
+    return ctx->Lmax <= 20000 || ctx->n_reads <= 2;
+}
+
+static mtr_status launch_staged(mtr_ctx *ctx)
+{
+    const int n = ctx->n_reads;
+    int64_t sumL = 0; for (int i = 0; i < n; i++) sumL += ctx->lens[(size_t)i];
+    StagedArgs s{};
+    s.n_reads = n;
+    s.arena_cap = sumL * 48 + (1 << 20);
+    s.kc_cap = (int32_t)std::min<int64_t>(ctx->total_rcap, sumL / 8 + 4096);
+    s.dp_cap = (int32_t)std::min<int64_t>(0x7fffff00, sumL / 8 + 4096);
+    s.sorted_cap = s.dp_cap + 64 * 512;
+    s.cand_cap = n * 8 + 1024;
+    {
+        size_t free_b = 0, tot_b = 0;
+        if (hipMemGetInfo(&free_b, &tot_b) != hipSuccess) free_b = (size_t)16 << 30;
+        int64_t want = std::max<int64_t>(sumL * 1024, (int64_t)256 << 20);
+        const char *e = getenv("MTR_STAGED_CODES_GB");
+        if (e) want = (int64_t)(atof(e) * (double)(1ll << 30));
+        s.codes_cap = std::min<int64_t>(want, (int64_t)((double)free_b * 0.5) + (ctx->d_st_codes ? want : 0));
+    }
+    HIPCHK(ensure_dev(ctx, ctx->d_st_arena, (size_t)s.arena_cap)); HIPCHK(ensure_dev(ctx, ctx->d_st_codes, (size_t)s.codes_cap));
+    HIPCHK(ensure_dev(ctx, ctx->d_st_kc, (size_t)s.kc_cap * 8)); HIPCHK(ensure_dev(ctx, ctx->d_st_dp, (size_t)s.dp_cap * sizeof(StDpItem)));
+    HIPCHK(ensure_dev(ctx, ctx->d_st_bincnt, (size_t)ST_NBINS * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_binstart, ((size_t)ST_NBINS + 1) * 4));
+    HIPCHK(ensure_dev(ctx, ctx->d_st_dpbin, (size_t)s.dp_cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_dprank, (size_t)s.dp_cap * 4));
+    HIPCHK(ensure_dev(ctx, ctx->d_st_sorted, (size_t)s.sorted_cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_classwave, 8 * 4));
+    HIPCHK(ensure_dev(ctx, ctx->d_st_cand, (size_t)s.cand_cap * sizeof(DevRecord))); HIPCHK(ensure_dev(ctx, ctx->d_st_flag, (size_t)std::max<int64_t>(ctx->total_rcap, 1) * 4));
+    HIPCHK(ensure_dev(ctx, ctx->d_st_scalars, 64 * 8));
+    HIPCHK(ensure_dev(ctx, ctx->d_st_wv, (size_t)s.dp_cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_res, (size_t)s.dp_cap * 16 * 4));
+    s.lane_umax = staged_lane_umax(); s.wv_items = ctx->d_st_wv; s.dp_res = ctx->d_st_res;
+    s.item_cap = (int32_t)std::min<int64_t>(0x7fffff00, ctx->total_rcap);
+    HIPCHK(ensure_dev(ctx, ctx->d_st_items, (size_t)std::max(s.item_cap, 1) * sizeof(int4)));
+    s.item_tab = ctx->d_st_items;
+    unsigned long long *sc = ctx->d_st_scalars;
+    s.item_off = ctx->d_item_off; s.n_items = (int32_t *)(sc + 0);
+    s.arena = ctx->d_st_arena; s.arena_cur = sc + 1;
+    s.kc_items = (long long *)ctx->d_st_kc; s.n_kc = (unsigned *)(sc + 2);
+    s.dp = ctx->d_st_dp; s.n_dp = (unsigned *)(sc + 3);
+    s.codes = ctx->d_st_codes; s.codes_cur = sc + 4;
+    s.bin_count = ctx->d_st_bincnt; s.dp_bin = ctx->d_st_dpbin; s.dp_rank = ctx->d_st_dprank;
+    s.bin_start = ctx->d_st_binstart; s.sorted = ctx->d_st_sorted; s.class_wave = ctx->d_st_classwave;
+    s.cand = ctx->d_st_cand; s.n_cand = (unsigned *)(sc + 5); s.cand_flag = ctx->d_st_flag;
+    s.n_wv = (unsigned *)(sc + 6);
+    s.work = (unsigned *)(sc + 8);
+    K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
+    // few reads: the range finder as one wavefront per (read, pass) over per-READ scratch (launch_k1_parts), as in the
+    // range-parallel mode; the unit kernels then take their per-wavefront scratch behind it
+    const long parts_max = getenv("MTR_K1_PARTS_MAX_READS") ? atol(getenv("MTR_K1_PARTS_MAX_READS")) : 256;
+    bool parts = n <= parts_max;
+    if (parts) { size_t tot = 0; parts = pick_waves(ctx, n, n, y1.total, &tot) == n; }
+    const size_t per_wave = parts ? y2.total : std::max(y1.total, y2.total);
+    size_t total = 0;
+    const int waves = pick_waves(ctx, std::max(n * 8, ctx->n_cu * 16), waves_per_cu(), per_wave, &total);
+    const int waves1 = std::min(waves, n);
+    mtr_status st = ensure_scratch(ctx, std::max(total, parts ? (size_t)n * y1.total : (size_t)0)); if (st != MTR_OK) return st;
+    K1Args a1{}; k1_args(ctx, a1, per_wave);
+    K2Args a{}; k2_args(ctx, a, per_wave);
+    HIPCHK(hipMemsetAsync(ctx->d_trace_n, 0, sizeof(unsigned), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_st_scalars, 0, 64 * 8, ctx->stream));
+    if (s.lane_umax > 0) {
+        HIPCHK(hipMemsetAsync(ctx->d_st_bincnt, 0, (size_t)ST_NBINS * 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->d_st_sorted, 0xFF, (size_t)s.sorted_cap * 4, ctx->stream));
+    }
+    HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    if (parts) { mtr_status ps = launch_k1_parts(ctx); if (ps != MTR_OK) return ps; }
+    else {
+        HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
+        hipLaunchKernelGGL(mtr_k1_ranges, dim3((unsigned)waves1), dim3(64), 0, ctx->stream, a1);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(mtr_k_items, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)ctx->d_rcount, s);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(mtr_k_item_table, dim3((unsigned)std::min(n, 4096)), dim3(256), 0, ctx->stream, a, s);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(mtr_k_walks, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a, s);
+    HIPCHK(hipGetLastError());
+    if (s.lane_umax > 0) {
+        hipLaunchKernelGGL(mtr_k_bins, dim3(1), dim3(512), 0, ctx->stream, s);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(mtr_k_scatter, dim3(512), dim3(256), 0, ctx->stream, s);
+        HIPCHK(hipGetLastError());
+        const unsigned gdp = (unsigned)ctx->n_cu * 16u;
+        hipLaunchKernelGGL(mtr_k_dp2_lanes<16>, dim3(gdp), dim3(64), 0, ctx->stream, a, s, 0);
+        if (s.lane_umax > 16) hipLaunchKernelGGL(mtr_k_dp2_lanes<32>, dim3(gdp), dim3(64), 0, ctx->stream, a, s, 1);
+        if (s.lane_umax > 32) hipLaunchKernelGGL(mtr_k_dp2_lanes<64>, dim3(gdp), dim3(64), 0, ctx->stream, a, s, 2);
+        if (s.lane_umax > 64) hipLaunchKernelGGL(mtr_k_dp2_lanes<128>, dim3(gdp), dim3(64), 0, ctx->stream, a, s, 3);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(mtr_k_dp2_waves, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a, s);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(mtr_k_select, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a, s);
+    HIPCHK(hipGetLastError());
+    SplitArgs sp{};
+    sp.item_read = nullptr; sp.item_idx = nullptr; sp.item_off = ctx->d_item_off; sp.n_items = 0;
+    sp.cand = ctx->d_st_cand; sp.cand_flag = ctx->d_st_flag; sp.indirect = 1;
+    hipLaunchKernelGGL(mtr_k_replay, dim3((unsigned)std::min(n, 65535)), dim3(64), 0, ctx->stream, a, sp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+    return MTR_OK;
+}
+
 // A read gets max_rec = 16 + Lmax/100 record slots; the kernels count the records of a read that found more (about one
 // read in 10^5 of the synthetic sets) without storing them.  Such reads are run once more, alone, with exactly the room
 // they need (the ranges are recomputed: the unit phase prunes them in place); the compaction then takes their
@@ -698,8 +831,9 @@ extern "C" mtr_status mtr_run_resident_async(mtr_ctx *ctx)
     HIPCHK(hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_fail_read, 0x7f, 4, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
-    ctx->last_split = use_split(ctx);
-    mtr_status s = ctx->last_split ? launch_split(ctx) : launch_reads(ctx); if (s != MTR_OK) return s;
+    ctx->last_staged = use_staged(ctx);
+    ctx->last_split = !ctx->last_staged && use_split(ctx);
+    mtr_status s = ctx->last_staged ? launch_staged(ctx) : ctx->last_split ? launch_split(ctx) : launch_reads(ctx); if (s != MTR_OK) return s;
     ctx->pending = true;
     return MTR_OK;
 }
@@ -716,6 +850,29 @@ extern "C" mtr_status mtr_wait(mtr_ctx *ctx)
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->kt[1].ms = ms; ctx->kt[1].launches = 1;
     HIPCHK(copy_sync(ctx, ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
     mtr_status st = check_status(ctx);
+    if (ctx->last_staged && dbg()) {
+        unsigned long long sc[16]; int32_t cw[8];
+        if (copy_sync(ctx, sc, ctx->d_st_scalars, sizeof sc, hipMemcpyDeviceToHost) == hipSuccess && copy_sync(ctx, cw, ctx->d_st_classwave, sizeof cw, hipMemcpyDeviceToHost) == hipSuccess)
+            DBG("staged: items %d, ranges with candidates %u, DP items %u (%u one wavefront each), candidate arena %.1f MB, cells %.2f GB, records parked %u; wavefronts per unit-length class %d %d %d %d",
+                (int)(int32_t)sc[0], (unsigned)sc[2], (unsigned)sc[3], (unsigned)sc[6], (double)sc[1] / 1e6, (double)sc[4] / 1e9, (unsigned)sc[5], cw[1] - cw[0], cw[2] - cw[1], cw[3] - cw[2], cw[4] - cw[3]);
+    }
+    if (st == MTR_ERR_OVERFLOW && ctx->last_staged) {
+        // the batch outgrew a buffer of the staged mode: the per-read kernel takes it (same results)
+        int32_t dst = 0;
+        HIPCHK(copy_sync(ctx, &dst, ctx->d_status, 4, hipMemcpyDeviceToHost));
+        if (dst == DEV_ERR_STAGED_OVERFLOW) {
+            DBG("staged mode: buffer overflow, running the batch with the per-read kernel");
+            ctx->last_staged = false;
+            HIPCHK(hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+            HIPCHK(hipMemsetAsync(ctx->d_fail_read, 0x7f, 4, ctx->stream));
+            HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
+            { mtr_status ls = launch_reads(ctx); if (ls != MTR_OK) { ctx->run_status = ls; return ls; } }
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->kt[1].ms += ms; ctx->kt[1].launches = 2;
+            HIPCHK(copy_sync(ctx, ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
+            st = check_status(ctx);
+        }
+    }
     if (st == MTR_ERR_DP_TOO_LARGE) {
         int32_t fr = -1;
         if (copy_sync(ctx, &fr, ctx->d_fail_read, 4, hipMemcpyDeviceToHost) == hipSuccess && fr >= 0 && fr < ctx->n_reads) ctx->first_failed = fr;

@@ -47,7 +47,8 @@ enum { CNT_DP_CALLS = 0, CNT_DP_CELLS, CNT_DP_ROWS, CNT_REV_CALLS, CNT_REV_CELLS
        CNT_N = 48 };
 
 // status word values written by the kernels (first error wins)
-enum { DEV_OK = 0, DEV_ERR_RANGE_OVERFLOW = 1, DEV_ERR_RECORD_OVERFLOW = 2, DEV_ERR_DP_TOO_LARGE = 3, DEV_ERR_INTERNAL = 4 };
+enum { DEV_OK = 0, DEV_ERR_RANGE_OVERFLOW = 1, DEV_ERR_RECORD_OVERFLOW = 2, DEV_ERR_DP_TOO_LARGE = 3, DEV_ERR_INTERNAL = 4,
+       DEV_ERR_STAGED_OVERFLOW = 5 };    // a buffer of the staged mode was too small: the host reruns the batch with the per-read kernel
 
 static inline __host__ __device__ int mtrc_rand_len(int L) { return L < 1000 ? 100 : L / 10; }   // handle_one_read.c:194-201
 static inline __host__ __device__ size_t mtrc_align(size_t x, size_t a) { return (x + a - 1) / a * a; }

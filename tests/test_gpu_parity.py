@@ -262,12 +262,22 @@ def test_read_of_the_maximum_length(eng, oracle):
         eng.process([np.zeros(833334, np.uint8)])
 
 
-# ---- range-parallel mode (small batches): same records as one wavefront per read -----------------------------------
-@pytest.mark.parametrize("split", ["0", "1"])
-def test_range_parallel_mode_matches(monkeypatch, oracle, split):
-    """MTR_SPLIT=1 searches every candidate range as its own work item and replays the reference's sequential pruning;
-    MTR_SPLIT=0 forces one wavefront per read.  Both must give the oracle's records (and so each other's)."""
-    monkeypatch.setenv("MTR_SPLIT", split)
+# ---- the kernel modes: same records as one wavefront per read -----------------------------------------------------------
+MODES = {"per_read": {"MTR_STAGED": "0", "MTR_SPLIT": "0"}, "range_parallel": {"MTR_STAGED": "0", "MTR_SPLIT": "1"},
+         "staged": {"MTR_STAGED": "1"}, "staged_lanes16": {"MTR_STAGED": "1", "MTR_STAGED_LANE_UMAX": "16"},
+         "staged_lanes128": {"MTR_STAGED": "1", "MTR_STAGED_LANE_UMAX": "128"},
+         "staged_overflow": {"MTR_STAGED": "1", "MTR_STAGED_LANE_UMAX": "128", "MTR_STAGED_CODES_GB": "0.001"}}
+
+
+@pytest.mark.parametrize("mode", sorted(MODES))
+def test_kernel_modes_match_the_oracle(monkeypatch, oracle, mode):
+    """per_read: one wavefront per read (the reference's sequential range loop).  range_parallel: every candidate range its
+    own work item + replay of the sequential pruning.  staged: ranges -> walks -> every two-parameter DP its own work item
+    (one wavefront each, or with MTR_STAGED_LANE_UMAX one DP per LANE for short units) -> selection/revision -> replay;
+    staged_overflow: a cell arena far too small, so the library must fall back to the per-read kernel.  All must give
+    the oracle's records (and so each other's)."""
+    for k, v in MODES[mode].items():
+        monkeypatch.setenv(k, v)
     e = mtr_amd.Engine()
     rng = np.random.RandomState(7)
     reads = [c for _, c in synth.make_reads("headline2k", 40, 91)] + [c for _, c in synth.make_reads("c4", 40, 92)]
@@ -280,8 +290,10 @@ def test_range_parallel_mode_matches(monkeypatch, oracle, split):
     e.close()
 
 
-def test_range_parallel_mode_golden(monkeypatch):
-    monkeypatch.setenv("MTR_SPLIT", "1")
+@pytest.mark.parametrize("mode", ["range_parallel", "staged", "staged_lanes128"])
+def test_kernel_modes_golden(monkeypatch, mode):
+    for k, v in MODES[mode].items():
+        monkeypatch.setenv(k, v)
     engines = {"default": mtr_amd.Engine(manhattan=True), "p": mtr_amd.Engine(manhattan=False)}
     checked = 0
     for name, mode in gu.cases():
@@ -349,13 +361,17 @@ def _file_order_case():
     return reads
 
 
-@pytest.mark.parametrize("manhattan,split", [(True, "0"), (True, "1"), (False, "0"), (False, "1")])
+@pytest.mark.parametrize("manhattan,split", [(True, "0"), (True, "1"), (False, "0"), (False, "1"), (True, "staged"), (False, "staged")])
 def test_file_order_mode_matches_reference_behaviour_on_a_file(monkeypatch, manhattan, split):
     """mtr_upload_batch_in_file: the records equal the oracle's file-order mode (pinned to the reference run on whole
     files, tests/test_oracle_golden.py) whatever the batch boundaries, in both kernel modes; and they differ from the
     isolated records on this input, so the test can fail."""
     from tests.oracle_binding import Oracle
-    monkeypatch.setenv("MTR_SPLIT", split)
+    if split == "staged":
+        monkeypatch.setenv("MTR_STAGED", "1")
+    else:
+        monkeypatch.setenv("MTR_STAGED", "0")
+        monkeypatch.setenv("MTR_SPLIT", split)
     reads = _file_order_case()
     o = Oracle(manhattan)
     o.set_file_order(True)

@@ -700,14 +700,16 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     int64_t sumL = 0; for (int i = 0; i < n; i++) sumL += ctx->lens[(size_t)i];
     StagedArgs s{};
     s.n_reads = n;
-    s.arena_cap = sumL * 48 + (1 << 20);
+    size_t free_b = 0, tot_b = 0;
+    if (hipMemGetInfo(&free_b, &tot_b) != hipSuccess) free_b = (size_t)16 << 30;
+    // parked candidates: 5 bytes per unit base; reads of long units (unit 200 x 200 copies: ~1 KB per candidate, ~20 per
+    // range) need two orders of magnitude more per base than 2 kb reads (8 bytes per base measured)
+    s.arena_cap = std::min<int64_t>(sumL * 1024 + (1 << 20), (int64_t)((double)free_b * 0.2) + (ctx->d_st_arena ? sumL * 1024 : 0));
     s.kc_cap = (int32_t)std::min<int64_t>(ctx->total_rcap, sumL / 8 + 4096);
     s.dp_cap = (int32_t)std::min<int64_t>(0x7fffff00, sumL / 8 + 4096);
     s.sorted_cap = s.dp_cap + 64 * 512;
-    s.cand_cap = n * 8 + 1024;
+    s.cand_cap = (int32_t)std::min<int64_t>(0x7fffff00, (int64_t)n * 8 + sumL / 256 + 1024);
     {
-        size_t free_b = 0, tot_b = 0;
-        if (hipMemGetInfo(&free_b, &tot_b) != hipSuccess) free_b = (size_t)16 << 30;
         int64_t want = std::max<int64_t>(sumL * 1024, (int64_t)256 << 20);
         const char *e = getenv("MTR_STAGED_CODES_GB");
         if (e) want = (int64_t)(atof(e) * (double)(1ll << 30));
@@ -746,7 +748,9 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     size_t total = 0;
     const int waves = pick_waves(ctx, std::max(n * 8, ctx->n_cu * 16), waves_per_cu(), per_wave, &total);
     const int waves1 = std::min(waves, n);
-    mtr_status st = ensure_scratch(ctx, std::max(total, parts ? (size_t)n * y1.total : (size_t)0)); if (st != MTR_OK) return st;
+    size_t total_dp = 0;                                    // the per-DP kernel runs at twice the occupancy (no LDS table, 64 VGPRs)
+    const int waves_dp = pick_waves(ctx, std::max(n * 8, ctx->n_cu * 32), 32, per_wave, &total_dp);
+    mtr_status st = ensure_scratch(ctx, std::max(std::max(total, total_dp), parts ? (size_t)n * y1.total : (size_t)0)); if (st != MTR_OK) return st;
     K1Args a1{}; k1_args(ctx, a1, per_wave);
     K2Args a{}; k2_args(ctx, a, per_wave);
     HIPCHK(hipMemsetAsync(ctx->d_trace_n, 0, sizeof(unsigned), ctx->stream));
@@ -780,7 +784,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         if (s.lane_umax > 64) hipLaunchKernelGGL(mtr_k_dp2_lanes<128>, dim3(gdp), dim3(64), 0, ctx->stream, a, s, 3);
         HIPCHK(hipGetLastError());
     }
-    hipLaunchKernelGGL(mtr_k_dp2_waves, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a, s);
+    hipLaunchKernelGGL(mtr_k_dp2_waves, dim3((unsigned)waves_dp), dim3(64), 0, ctx->stream, a, s);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(mtr_k_select, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a, s);
     HIPCHK(hipGetLastError());

@@ -82,6 +82,8 @@ struct mtr_ctx {
     unsigned *d_st_bincnt = nullptr; int32_t *d_st_dpbin = nullptr, *d_st_dprank = nullptr, *d_st_binstart = nullptr, *d_st_sorted = nullptr, *d_st_classwave = nullptr;
     DevRecord *d_st_cand = nullptr; int32_t *d_st_flag = nullptr; unsigned long long *d_st_scalars = nullptr;
     int32_t *d_st_wv = nullptr, *d_st_res = nullptr; int4 *d_st_items = nullptr;
+    // cost-ordered queue of the per-read unit kernel
+    unsigned *d_lpt_count = nullptr; int32_t *d_lpt_start = nullptr, *d_lpt_bin = nullptr, *d_lpt_rank = nullptr, *d_lpt_order = nullptr;
     std::vector<std::pair<void *, size_t>> caps;       // (address of the pointer member, bytes allocated)
     // reads that found more records than their max_rec slots are run again with room for all of them (resolve_overflow)
     std::vector<int32_t> ovf_reads; int ovf_cap = 0;
@@ -245,6 +247,7 @@ static void release_batch_buffers(mtr_ctx *ctx)
     dfree(ctx->d_tail); dfree(ctx->d_tail_off);
     dfree(ctx->d_st_arena); dfree(ctx->d_st_codes); dfree(ctx->d_st_kc); dfree(ctx->d_st_dp); dfree(ctx->d_st_bincnt); dfree(ctx->d_st_dpbin); dfree(ctx->d_st_dprank);
     dfree(ctx->d_st_binstart); dfree(ctx->d_st_sorted); dfree(ctx->d_st_classwave); dfree(ctx->d_st_cand); dfree(ctx->d_st_flag); dfree(ctx->d_st_scalars); dfree(ctx->d_st_wv); dfree(ctx->d_st_res); dfree(ctx->d_st_items);
+    dfree(ctx->d_lpt_count); dfree(ctx->d_lpt_start); dfree(ctx->d_lpt_bin); dfree(ctx->d_lpt_rank); dfree(ctx->d_lpt_order);
     dfree(ctx->d_wire_bytes); dfree(ctx->d_wire_off); dfree(ctx->d_wire);
     dfree(ctx->d_al_i32); dfree(ctx->d_al_len); dfree(ctx->d_al_ends); dfree(ctx->d_al_units); dfree(ctx->d_al_ops); dfree(ctx->d_al_off);
     dfree(ctx->d_t_i32); dfree(ctx->d_t_out); dfree(ctx->d_t_units);
@@ -557,33 +560,49 @@ static void k2_args(mtr_ctx *ctx, K2Args &a, size_t per_wave)
     a.dp16_max_rows = dp16_max_rows();
 }
 
-// File-order mode with one wavefront per read: the range kernel (it reads the stale tails) and the unit kernel, each
-// with its own scratch layout over the same allocation.
-static mtr_status launch_file_order(mtr_ctx *ctx)
+// One wavefront per read as TWO kernels: the range kernel, then the unit kernel (mtr_k_units) with its work queue ordered by
+// the predicted cost of the reads (k3_staged.hip.inc: mtr_k_cost_*), each with its own scratch layout over the same
+// allocation.  The file-order mode always runs this way (its range kernel reads the stale tails); MTR_LPT=1 chooses it for
+// isolated semantics too.
+static mtr_status launch_two_kernels(mtr_ctx *ctx)
 {
+    const int n = ctx->n_reads;
     K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
     size_t t1 = 0, t2 = 0;
-    const int w1 = pick_waves(ctx, ctx->n_reads, waves_per_cu(), y1.total, &t1);
-    const int w2 = pick_waves(ctx, ctx->n_reads, waves_per_cu(), y2.total, &t2);
+    const int w1 = pick_waves(ctx, n, waves_per_cu(), y1.total, &t1);
+    const int w2 = pick_waves(ctx, n, waves_per_cu(), y2.total, &t2);
     mtr_status s = ensure_scratch(ctx, std::max(t1, t2)); if (s != MTR_OK) return s;
+    HIPCHK(ensure_dev(ctx, ctx->d_lpt_count, (size_t)LPT_BINS * 4)); HIPCHK(ensure_dev(ctx, ctx->d_lpt_start, (size_t)LPT_BINS * 4));
+    HIPCHK(ensure_dev(ctx, ctx->d_lpt_bin, (size_t)n * 4)); HIPCHK(ensure_dev(ctx, ctx->d_lpt_rank, (size_t)n * 4)); HIPCHK(ensure_dev(ctx, ctx->d_lpt_order, (size_t)n * 4));
     K1Args a1{}; k1_args(ctx, a1, y1.total);
     K2Args a{}; k2_args(ctx, a, y2.total);
     HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_trace_n, 0, sizeof(unsigned), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_lpt_count, 0, (size_t)LPT_BINS * 4, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     hipLaunchKernelGGL(mtr_k1_ranges, dim3((unsigned)w1), dim3(64), 0, ctx->stream, a1);
     HIPCHK(hipGetLastError());
+    if (!ctx->sub_active) {                              // (the few reads of an overflow rerun keep their order)
+        const unsigned g = (unsigned)std::min(1024, (n + 255) / 256);
+        hipLaunchKernelGGL(mtr_k_cost_bins, dim3(g), dim3(256), 0, ctx->stream, a, ctx->d_lpt_count, ctx->d_lpt_bin, ctx->d_lpt_rank);
+        hipLaunchKernelGGL(mtr_k_cost_scan, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned *)ctx->d_lpt_count, ctx->d_lpt_start);
+        hipLaunchKernelGGL(mtr_k_cost_order, dim3(g), dim3(256), 0, ctx->stream, (int32_t)n, (const int32_t *)ctx->d_lpt_start, (const int32_t *)ctx->d_lpt_bin,
+                           (const int32_t *)ctx->d_lpt_rank, ctx->d_lpt_order);
+        HIPCHK(hipGetLastError());
+        a.b.order = ctx->d_lpt_order;
+    }
     HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
     hipLaunchKernelGGL(mtr_k_units, dim3((unsigned)w2), dim3(64), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
     return MTR_OK;
 }
+static bool use_lpt() { const char *e = getenv("MTR_LPT"); return e && atoi(e) != 0; }
 
 // the per-read kernel: ranges (K1 code) and unit search / DP (K2 code) of a read by the same wavefront
 static mtr_status launch_reads(mtr_ctx *ctx)
 {
-    if (ctx->file_order) return launch_file_order(ctx);
+    if (ctx->file_order || use_lpt()) return launch_two_kernels(ctx);
     K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
     const size_t per_wave = std::max(y1.total, y2.total);       // the two phases of a read use the arena one after the other
     size_t total = 0;

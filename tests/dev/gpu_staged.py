@@ -5,7 +5,7 @@ to U bases aligned one DP per lane and the others one wavefront per DP."""
 import os, sys, time, subprocess, pickle
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-MODES = [("fused", dict(MTR_STAGED="0", MTR_SPLIT="0")), ("split", dict(MTR_STAGED="0", MTR_SPLIT="1")),
+MODES = [("fused", dict(MTR_STAGED="0", MTR_SPLIT="0")), ("lpt", dict(MTR_STAGED="0", MTR_SPLIT="0", MTR_LPT="1")), ("split", dict(MTR_STAGED="0", MTR_SPLIT="1")),
          ("staged0", dict(MTR_STAGED="1", MTR_STAGED_LANE_UMAX="0")), ("staged16", dict(MTR_STAGED="1", MTR_STAGED_LANE_UMAX="16")),
          ("staged128", dict(MTR_STAGED="1", MTR_STAGED_LANE_UMAX="128"))]
 

@@ -81,7 +81,7 @@ struct mtr_ctx {
     uint8_t *d_st_arena = nullptr, *d_st_codes = nullptr; int64_t *d_st_kc = nullptr; StDpItem *d_st_dp = nullptr;
     unsigned *d_st_bincnt = nullptr; int32_t *d_st_dpbin = nullptr, *d_st_dprank = nullptr, *d_st_binstart = nullptr, *d_st_sorted = nullptr, *d_st_classwave = nullptr;
     DevRecord *d_st_cand = nullptr; int32_t *d_st_flag = nullptr; unsigned long long *d_st_scalars = nullptr;
-    int32_t *d_st_wv = nullptr, *d_st_res = nullptr; int4 *d_st_items = nullptr;
+    int32_t *d_st_wv = nullptr, *d_st_res = nullptr; int4 *d_st_items = nullptr, *d_st_cont = nullptr;
     // cost-ordered queue of the per-read unit kernel
     unsigned *d_lpt_count = nullptr; int32_t *d_lpt_start = nullptr, *d_lpt_bin = nullptr, *d_lpt_rank = nullptr, *d_lpt_order = nullptr;
     std::vector<std::pair<void *, size_t>> caps;       // (address of the pointer member, bytes allocated)
@@ -246,7 +246,7 @@ static void release_batch_buffers(mtr_ctx *ctx)
     dfree(ctx->d_item_read); dfree(ctx->d_item_idx); dfree(ctx->d_cand_flag); dfree(ctx->d_item_off); dfree(ctx->d_cand); ctx->item_cap = 0;
     dfree(ctx->d_tail); dfree(ctx->d_tail_off);
     dfree(ctx->d_st_arena); dfree(ctx->d_st_codes); dfree(ctx->d_st_kc); dfree(ctx->d_st_dp); dfree(ctx->d_st_bincnt); dfree(ctx->d_st_dpbin); dfree(ctx->d_st_dprank);
-    dfree(ctx->d_st_binstart); dfree(ctx->d_st_sorted); dfree(ctx->d_st_classwave); dfree(ctx->d_st_cand); dfree(ctx->d_st_flag); dfree(ctx->d_st_scalars); dfree(ctx->d_st_wv); dfree(ctx->d_st_res); dfree(ctx->d_st_items);
+    dfree(ctx->d_st_binstart); dfree(ctx->d_st_sorted); dfree(ctx->d_st_classwave); dfree(ctx->d_st_cand); dfree(ctx->d_st_flag); dfree(ctx->d_st_scalars); dfree(ctx->d_st_wv); dfree(ctx->d_st_res); dfree(ctx->d_st_items); dfree(ctx->d_st_cont);
     dfree(ctx->d_lpt_count); dfree(ctx->d_lpt_start); dfree(ctx->d_lpt_bin); dfree(ctx->d_lpt_rank); dfree(ctx->d_lpt_order);
     dfree(ctx->d_wire_bytes); dfree(ctx->d_wire_off); dfree(ctx->d_wire);
     dfree(ctx->d_al_i32); dfree(ctx->d_al_len); dfree(ctx->d_al_ends); dfree(ctx->d_al_units); dfree(ctx->d_al_ops); dfree(ctx->d_al_off);
@@ -703,14 +703,12 @@ static bool use_staged(const mtr_ctx *ctx)
     const char *e = getenv("MTR_STAGED");
     if (e) return atoi(e) != 0;
     if (getenv("MTR_SPLIT")) return false;                 // an explicit choice between the two older modes
-    // [measured, host call on one resident batch of 2 kb reads] 1 read: 3.2 ms (range-parallel mode 9 ms, per-read kernel
-    // 19 ms); 64: 12 / 16 / 30 ms; 2 000: 30 / 35 / 39 ms; 10 000: 87 / 98 / 79 ms -> up to MTR_STAGED_MAX_READS (6 000)
-    // reads.  Batches of long reads keep the range-parallel mode: its ranges run through all phases without a barrier
-    // between them (16 reads of 42 kb: 180 ms against 236 ms), except a single read (141 against 176 ms).
+    // [measured, host call on one resident batch of 2 kb reads: staged / range-parallel / per-read kernel] 1 read: 3.1 / 9 / 19 ms;
+    // 64: 10 / 16 / 30 ms; 2 000: 30 / 29-37 / 39 ms; 10 000: 97 / 98 / 77 ms; 100 reads of 42 kb: 275 / 289 / 1 148 ms
+    // -> the staged mode up to MTR_STAGED_MAX_READS (6 000) reads, the per-read kernel above.
     const char *m = getenv("MTR_STAGED_MAX_READS");
     const long max_reads = m ? atol(m) : 6000;
-    if (ctx->n_reads > max_reads) return false;
-    return ctx->Lmax <= 20000 || ctx->n_reads <= 2;
+    return ctx->n_reads <= max_reads;
 }
 
 static mtr_status launch_staged(mtr_ctx *ctx)
@@ -746,6 +744,10 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     s.item_cap = (int32_t)std::min<int64_t>(0x7fffff00, ctx->total_rcap);
     HIPCHK(ensure_dev(ctx, ctx->d_st_items, (size_t)std::max(s.item_cap, 1) * sizeof(int4)));
     s.item_tab = ctx->d_st_items;
+    s.cont_cap = (int32_t)std::min<int64_t>(0x7fffff00, 2 * (int64_t)s.kc_cap);
+    HIPCHK(ensure_dev(ctx, ctx->d_st_cont, (size_t)s.cont_cap * sizeof(int4)));
+    s.cont = ctx->d_st_cont;
+    s.k_first = getenv("MTR_STAGED_K_FIRST") ? std::max(1, atoi(getenv("MTR_STAGED_K_FIRST"))) : 3;
     unsigned long long *sc = ctx->d_st_scalars;
     s.item_off = ctx->d_item_off; s.n_items = (int32_t *)(sc + 0);
     s.arena = ctx->d_st_arena; s.arena_cur = sc + 1;
@@ -755,7 +757,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     s.bin_count = ctx->d_st_bincnt; s.dp_bin = ctx->d_st_dpbin; s.dp_rank = ctx->d_st_dprank;
     s.bin_start = ctx->d_st_binstart; s.sorted = ctx->d_st_sorted; s.class_wave = ctx->d_st_classwave;
     s.cand = ctx->d_st_cand; s.n_cand = (unsigned *)(sc + 5); s.cand_flag = ctx->d_st_flag;
-    s.n_wv = (unsigned *)(sc + 6);
+    s.n_wv = (unsigned *)(sc + 6); s.n_cont = (unsigned *)(sc + 7);
     s.work = (unsigned *)(sc + 8);
     K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
     // few reads: the range finder as one wavefront per (read, pass) over per-READ scratch (launch_k1_parts), as in the
@@ -789,8 +791,21 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(mtr_k_item_table, dim3((unsigned)std::min(n, 4096)), dim3(256), 0, ctx->stream, a, s);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(mtr_k_walks, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a, s);
-    HIPCHK(hipGetLastError());
+    {   // the walks align nothing: a scratch layout without the cell region, and as many wavefronts as the occupancy allows
+        K2Args aw = a;
+        aw.cells_cap = 256;
+        const size_t pw = k2_layout(ctx->Lmax, aw.cells_cap).total;
+        size_t tw = 0;
+        int ww = pick_waves(ctx, std::max(n * 8, ctx->n_cu * 16), waves_per_cu(), pw, &tw);
+        if (tw > ctx->scratch_bytes) ww = std::min(ww, waves);
+        aw.scratch_per_wave = pw;
+        hipLaunchKernelGGL(mtr_k_walks, dim3((unsigned)ww), dim3(64), 0, ctx->stream, aw, s);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(mtr_k_walks_k, dim3((unsigned)ww), dim3(64), 0, ctx->stream, aw, s);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(mtr_k_gather, dim3((unsigned)ctx->n_cu * 16u), dim3(64), 0, ctx->stream, a, s);
+        HIPCHK(hipGetLastError());
+    }
     if (s.lane_umax > 0) {
         hipLaunchKernelGGL(mtr_k_bins, dim3(1), dim3(512), 0, ctx->stream, s);
         HIPCHK(hipGetLastError());
@@ -876,8 +891,8 @@ extern "C" mtr_status mtr_wait(mtr_ctx *ctx)
     if (ctx->last_staged && dbg()) {
         unsigned long long sc[16]; int32_t cw[8];
         if (copy_sync(ctx, sc, ctx->d_st_scalars, sizeof sc, hipMemcpyDeviceToHost) == hipSuccess && copy_sync(ctx, cw, ctx->d_st_classwave, sizeof cw, hipMemcpyDeviceToHost) == hipSuccess)
-            DBG("staged: items %d, ranges with candidates %u, DP items %u (%u one wavefront each), candidate arena %.1f MB, cells %.2f GB, records parked %u; wavefronts per unit-length class %d %d %d %d",
-                (int)(int32_t)sc[0], (unsigned)sc[2], (unsigned)sc[3], (unsigned)sc[6], (double)sc[1] / 1e6, (double)sc[4] / 1e9, (unsigned)sc[5], cw[1] - cw[0], cw[2] - cw[1], cw[3] - cw[2], cw[4] - cw[3]);
+            DBG("staged: items %d, ranges with a block %u (+ %u per-k work items), DP items %u (%u one wavefront each), candidate arena %.1f MB, cells %.2f GB, records parked %u; wavefronts per unit-length class %d %d %d %d",
+                (int)(int32_t)sc[0], (unsigned)sc[2], (unsigned)sc[7], (unsigned)sc[3], (unsigned)sc[6], (double)sc[1] / 1e6, (double)sc[4] / 1e9, (unsigned)sc[5], cw[1] - cw[0], cw[2] - cw[1], cw[3] - cw[2], cw[4] - cw[3]);
     }
     if (st == MTR_ERR_OVERFLOW && ctx->last_staged) {
         // the batch outgrew a buffer of the staged mode: the per-read kernel takes it (same results)

@@ -137,10 +137,13 @@ static inline __host__ __device__ size_t k2_max_cells(int Lmax)
     if (c > MTRC_WRAP_DP_SIZE) c = MTRC_WRAP_DP_SIZE;
     return (size_t)c;
 }
-static inline __host__ __device__ K2Layout k2_layout(int Lmax)
+// cells_cap > 0: a layout whose traceback-cell region holds only that many bytes (the kernels of the staged mode that
+// align nothing need none of it: the walks of 42 kb reads take 1.3 MB per wavefront instead of 21 MB)
+static inline __host__ __device__ K2Layout k2_layout(int Lmax, long long cells_cap = 0)
 {
     K2Layout y;
     y.cells = k2_max_cells(Lmax);
+    if (cells_cap > 0 && (size_t)cells_cap < y.cells) y.cells = (size_t)cells_cap;
     unsigned g = 2048; while (g < 2u * (unsigned)(Lmax + 2)) g <<= 1;
     y.gcap = g;
     size_t o = 0;
@@ -212,6 +215,7 @@ struct K2Args {
     int32_t *fail_read;            // atomicMin of the index of a read whose DP exceeded WrapDPsize (the reference exits there)
     int32_t *trace; int32_t trace_cap; unsigned int *trace_n; int32_t trace_mask;   // bit t = record events of type t
     int32_t dp16_max_rows;         // DPs of up to this many rows may use the 16-bit kernels (tests set 0 to force the 32-bit ones)
+    long long cells_cap;           // > 0: the scratch layout's cell region is this small (k2_layout)
 };
 
 // -a alignments (pretty_print_alignment, wrap_around_DP.c:57-213) of a list of reported repeats of the resident batch

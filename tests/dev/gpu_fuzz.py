@@ -74,13 +74,15 @@ def main():
                 for i, w in zip(order[j::56], ch):
                     want[i] = w
             t_or = time.time() - t0
-            for split in ("0", "1"):
-                os.environ["MTR_SPLIT"] = split
+            modes = {"per-read": dict(MTR_STAGED="0", MTR_SPLIT="0"), "range-parallel": dict(MTR_STAGED="0", MTR_SPLIT="1"),
+                     "staged": dict(MTR_STAGED="1", MTR_STAGED_LANE_UMAX="0"), "staged+lanes128": dict(MTR_STAGED="1", MTR_STAGED_LANE_UMAX="128")}
+            for split in modes:
+                os.environ.update(modes[split])
                 eng = mtr_amd.Engine(manhattan=manhattan)
                 t0 = time.time(); got = eng.process(reads); t_gpu = time.time() - t0
                 bad = [i for i in range(len(reads)) if [tuple(r) for r in got[i]] != want[i]]
                 bad_total += len(bad)
-                print(f"seed {seed} {'manhattan' if manhattan else 'pearson  '} MTR_SPLIT={split}: {len(reads)} reads ({sum(map(len, reads)) / 1e6:.1f} Mb, "
+                print(f"seed {seed} {'manhattan' if manhattan else 'pearson  '} {split}: {len(reads)} reads ({sum(map(len, reads)) / 1e6:.1f} Mb, "
                       f"{sum(len(w) for w in want)} records), {len(bad)} differ (gpu {t_gpu:.2f} s, oracle pool {t_or:.1f} s)"
                       f"{' first: ' + str([(i, len(reads[i])) for i in bad[:5]]) if bad else ''}", flush=True)
                 eng.close()

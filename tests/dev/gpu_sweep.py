@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Broad parity sweep (development aid): thousands of seeded reads of every synthetic config, both kernel modes, Manhattan
+"""Broad parity sweep (development aid): thousands of seeded reads of every synthetic config, every kernel mode, Manhattan
 and Pearson, against the CPU oracle (run in a process pool)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,13 +30,16 @@ def main():
             t0 = time.time()
             want = [w for ch in pool.map(oracle_chunk, [(manhattan, c) for c in chunks]) for w in ch]
             t_or = time.time() - t0
-            for split in (("0",) if len(reads) > 20000 else ("0", "1")):
-                os.environ["MTR_SPLIT"] = split
+            modes = {"per-read": dict(MTR_STAGED="0", MTR_SPLIT="0", MTR_LPT="0"), "cost-ordered": dict(MTR_STAGED="0", MTR_SPLIT="0", MTR_LPT="1"),
+                     "range-parallel": dict(MTR_STAGED="0", MTR_SPLIT="1", MTR_LPT="0"), "staged": dict(MTR_STAGED="1", MTR_STAGED_LANE_UMAX="0", MTR_LPT="0"),
+                     "staged+lanes64": dict(MTR_STAGED="1", MTR_STAGED_LANE_UMAX="64", MTR_LPT="0")}
+            for split in (("per-read", "staged") if len(reads) > 20000 else tuple(modes)):
+                os.environ.update(modes[split])
                 eng = mtr_amd.Engine(manhattan=manhattan)
                 t0 = time.time(); got = eng.process(reads); t_gpu = time.time() - t0
                 bad = [i for i in range(len(reads)) if [tuple(r) for r in got[i]] != want[i]]
                 bad_total += len(bad)
-                print(f"{cfg:11s} seed {seed} {'manhattan' if manhattan else 'pearson  '} MTR_SPLIT={split}: {len(reads)} reads, {len(bad)} differ"
+                print(f"{cfg:11s} seed {seed} {'manhattan' if manhattan else 'pearson  '} {split}: {len(reads)} reads, {len(bad)} differ"
                       f" (gpu {t_gpu:.2f} s, oracle pool {t_or:.1f} s){' first: ' + str(bad[:5]) if bad else ''}", flush=True)
                 eng.close()
     print("TOTAL MISMATCHES:", bad_total)

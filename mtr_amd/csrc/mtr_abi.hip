@@ -81,7 +81,7 @@ struct mtr_ctx {
     uint8_t *d_st_arena = nullptr, *d_st_codes = nullptr; int64_t *d_st_kc = nullptr; StDpItem *d_st_dp = nullptr;
     unsigned *d_st_bincnt = nullptr; int32_t *d_st_dpbin = nullptr, *d_st_dprank = nullptr, *d_st_binstart = nullptr, *d_st_sorted = nullptr, *d_st_classwave = nullptr;
     DevRecord *d_st_cand = nullptr; int32_t *d_st_flag = nullptr; unsigned long long *d_st_scalars = nullptr;
-    int32_t *d_st_wv = nullptr, *d_st_res = nullptr; int4 *d_st_items = nullptr, *d_st_cont = nullptr;
+    int32_t *d_st_wv = nullptr, *d_st_res = nullptr; int4 *d_st_items = nullptr, *d_st_cont = nullptr; int64_t *d_st_rev = nullptr;
     // cost-ordered queue of the per-read unit kernel
     unsigned *d_lpt_count = nullptr; int32_t *d_lpt_start = nullptr, *d_lpt_bin = nullptr, *d_lpt_rank = nullptr, *d_lpt_order = nullptr;
     std::vector<std::pair<void *, size_t>> caps;       // (address of the pointer member, bytes allocated)
@@ -246,7 +246,7 @@ static void release_batch_buffers(mtr_ctx *ctx)
     dfree(ctx->d_item_read); dfree(ctx->d_item_idx); dfree(ctx->d_cand_flag); dfree(ctx->d_item_off); dfree(ctx->d_cand); ctx->item_cap = 0;
     dfree(ctx->d_tail); dfree(ctx->d_tail_off);
     dfree(ctx->d_st_arena); dfree(ctx->d_st_codes); dfree(ctx->d_st_kc); dfree(ctx->d_st_dp); dfree(ctx->d_st_bincnt); dfree(ctx->d_st_dpbin); dfree(ctx->d_st_dprank);
-    dfree(ctx->d_st_binstart); dfree(ctx->d_st_sorted); dfree(ctx->d_st_classwave); dfree(ctx->d_st_cand); dfree(ctx->d_st_flag); dfree(ctx->d_st_scalars); dfree(ctx->d_st_wv); dfree(ctx->d_st_res); dfree(ctx->d_st_items); dfree(ctx->d_st_cont);
+    dfree(ctx->d_st_binstart); dfree(ctx->d_st_sorted); dfree(ctx->d_st_classwave); dfree(ctx->d_st_cand); dfree(ctx->d_st_flag); dfree(ctx->d_st_scalars); dfree(ctx->d_st_wv); dfree(ctx->d_st_res); dfree(ctx->d_st_items); dfree(ctx->d_st_cont); dfree(ctx->d_st_rev);
     dfree(ctx->d_lpt_count); dfree(ctx->d_lpt_start); dfree(ctx->d_lpt_bin); dfree(ctx->d_lpt_rank); dfree(ctx->d_lpt_order);
     dfree(ctx->d_wire_bytes); dfree(ctx->d_wire_off); dfree(ctx->d_wire);
     dfree(ctx->d_al_i32); dfree(ctx->d_al_len); dfree(ctx->d_al_ends); dfree(ctx->d_al_units); dfree(ctx->d_al_ops); dfree(ctx->d_al_off);
@@ -703,11 +703,11 @@ static bool use_staged(const mtr_ctx *ctx)
     const char *e = getenv("MTR_STAGED");
     if (e) return atoi(e) != 0;
     if (getenv("MTR_SPLIT")) return false;                 // an explicit choice between the two older modes
-    // [measured, host call on one resident batch of 2 kb reads: staged / range-parallel / per-read kernel] 1 read: 3.1 / 9 / 19 ms;
-    // 64: 10 / 16 / 30 ms; 2 000: 30 / 29-37 / 39 ms; 10 000: 97 / 98 / 77 ms; 100 reads of 42 kb: 275 / 289 / 1 148 ms
-    // -> the staged mode up to MTR_STAGED_MAX_READS (6 000) reads, the per-read kernel above.
+    // [measured, host call on one resident batch of 2 kb reads: staged / range-parallel / per-read kernel] 1 read: 3.1-3.4 / 9 / 19 ms;
+    // 64: 5.2 / 16 / 30 ms; 2 000: 26 / 35 / 40 ms; 2 000 config-4 reads: 26 / 53 / 53 ms; 6 000: 63 / 53 / 55 ms;
+    // 100 reads of 42 kb: 226 / 291 / 1 151 ms -> the staged mode up to MTR_STAGED_MAX_READS (4 000) reads, the per-read kernel above.
     const char *m = getenv("MTR_STAGED_MAX_READS");
-    const long max_reads = m ? atol(m) : 6000;
+    const long max_reads = m ? atol(m) : 4000;
     return ctx->n_reads <= max_reads;
 }
 
@@ -748,6 +748,9 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     HIPCHK(ensure_dev(ctx, ctx->d_st_cont, (size_t)s.cont_cap * sizeof(int4)));
     s.cont = ctx->d_st_cont;
     s.k_first = getenv("MTR_STAGED_K_FIRST") ? std::max(1, atoi(getenv("MTR_STAGED_K_FIRST"))) : 3;
+    s.rev_cap = s.kc_cap;
+    HIPCHK(ensure_dev(ctx, ctx->d_st_rev, (size_t)s.rev_cap * 8));
+    s.rev_items = (long long *)ctx->d_st_rev;
     unsigned long long *sc = ctx->d_st_scalars;
     s.item_off = ctx->d_item_off; s.n_items = (int32_t *)(sc + 0);
     s.arena = ctx->d_st_arena; s.arena_cur = sc + 1;
@@ -757,7 +760,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     s.bin_count = ctx->d_st_bincnt; s.dp_bin = ctx->d_st_dpbin; s.dp_rank = ctx->d_st_dprank;
     s.bin_start = ctx->d_st_binstart; s.sorted = ctx->d_st_sorted; s.class_wave = ctx->d_st_classwave;
     s.cand = ctx->d_st_cand; s.n_cand = (unsigned *)(sc + 5); s.cand_flag = ctx->d_st_flag;
-    s.n_wv = (unsigned *)(sc + 6); s.n_cont = (unsigned *)(sc + 7);
+    s.n_wv = (unsigned *)(sc + 6); s.n_cont = (unsigned *)(sc + 7); s.n_rev = (unsigned *)(sc + 16);
     s.work = (unsigned *)(sc + 8);
     K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
     // few reads: the range finder as one wavefront per (read, pass) over per-READ scratch (launch_k1_parts), as in the
@@ -821,6 +824,10 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     hipLaunchKernelGGL(mtr_k_dp2_waves, dim3((unsigned)waves_dp), dim3(64), 0, ctx->stream, a, s);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(mtr_k_select, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a, s);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(mtr_k_revise, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a, s);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(mtr_k_finish, dim3((unsigned)ctx->n_cu * 16u), dim3(64), 0, ctx->stream, a, s);
     HIPCHK(hipGetLastError());
     SplitArgs sp{};
     sp.item_read = nullptr; sp.item_idx = nullptr; sp.item_off = ctx->d_item_off; sp.n_items = 0;

@@ -704,10 +704,11 @@ static bool use_staged(const mtr_ctx *ctx)
     if (e) return atoi(e) != 0;
     if (getenv("MTR_SPLIT")) return false;                 // an explicit choice between the two older modes
     // [measured, host call on one resident batch of 2 kb reads: staged / range-parallel / per-read kernel] 1 read: 3.1-3.4 / 9 / 19 ms;
-    // 64: 5.2 / 16 / 30 ms; 2 000: 26 / 35 / 40 ms; 2 000 config-4 reads: 26 / 53 / 53 ms; 6 000: 63 / 53 / 55 ms;
-    // 100 reads of 42 kb: 226 / 291 / 1 151 ms -> the staged mode up to MTR_STAGED_MAX_READS (4 000) reads, the per-read kernel above.
+    // 64: 5.2 / 16 / 30 ms; 2 000: 26 / 35 / 40 ms; 2 000 config-4 reads: 26 / 53 / 53 ms; 3 000: 35 / 33 / 40; 4 000: 47 / 40 / 47;
+    // 6 000: 63 / 53 / 55 ms; 100 reads of 42 kb: 226 / 291 / 1 151 ms -> the staged mode up to MTR_STAGED_MAX_READS (3 000) reads,
+    // the range-parallel mode up to 4 096 (use_split), the per-read kernel above.
     const char *m = getenv("MTR_STAGED_MAX_READS");
-    const long max_reads = m ? atol(m) : 4000;
+    const long max_reads = m ? atol(m) : 3000;
     return ctx->n_reads <= max_reads;
 }
 

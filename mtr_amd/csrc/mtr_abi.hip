@@ -732,6 +732,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         const char *e = getenv("MTR_STAGED_CODES_GB");
         if (e) want = (int64_t)(atof(e) * (double)(1ll << 30));
         s.codes_cap = std::min<int64_t>(want, (int64_t)((double)free_b * 0.5) + (ctx->d_st_codes ? want : 0));
+        if (staged_lane_umax() == 0) s.codes_cap = 4096;        // the cell arena belongs to the lane kernels alone
     }
     HIPCHK(ensure_dev(ctx, ctx->d_st_arena, (size_t)s.arena_cap)); HIPCHK(ensure_dev(ctx, ctx->d_st_codes, (size_t)s.codes_cap));
     HIPCHK(ensure_dev(ctx, ctx->d_st_kc, (size_t)s.kc_cap * 8)); HIPCHK(ensure_dev(ctx, ctx->d_st_dp, (size_t)s.dp_cap * sizeof(StDpItem)));

@@ -55,12 +55,14 @@ OPS_PER_CELL = 7                 # ~7 integer ops per DP cell up
 
 
 def kernel_sources_sha():
+    # the sources of the dominant kernel (mtr_k_reads) and the flags it is built with; the host side of the library
+    # (mtr_abi.hip) and the staged mode's kernels (k3_staged.hip.inc) are not part of it
     h = hashlib.sha256()
     d = os.path.join(ROOT, "mtr_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".inc", ".hip", ".h")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in ("device_util.hip.inc", "dp_wrap.hip.inc", "k1_ranges.hip.inc", "k2_units.hip.inc", "mtr_common.h", "min_missing_table.h"):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "mtr_amd", "build.py"), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -166,10 +168,18 @@ def main():
     if a.gpus > 1 and world == 1:
         print("bench.py: --gpus > 1 needs torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
+    # MTR_BENCH_BACKEND=gloo: a rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share GPUs, the exchange
+    # goes through host memory); the driver's runs use RCCL ("nccl"), one GPU per rank
+    backend = os.environ.get("MTR_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
+    xdev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     if a.strong:
         # one data set for the whole job: every rank generates it (seeded) and keeps its contiguous block
@@ -202,11 +212,13 @@ def main():
         if wb is None or wb.numel() < need:
             wb = wire_buf[s % NCTX] = torch.empty(need * 5 // 4, dtype=torch.uint8, device="cuda")
         counts, total, nbytes = e.export_packed_device(wb.data_ptr(), wb.numel())
-        sizes = torch.tensor([nbytes, total, len(counts)], dtype=torch.int64, device="cuda")
+        sizes = torch.tensor([nbytes, total, len(counts)], dtype=torch.int64, device=xdev)
         all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
         dist.all_gather(all_sizes, sizes)
         width = max(int(x[0]) for x in all_sizes)
-        pad = wb[: max(width, 1)]
+        if wb.numel() < width:                          # another rank's table is larger than this rank's buffer: pad from a bigger one
+            nb = torch.zeros(width * 5 // 4, dtype=torch.uint8, device="cuda"); nb[: wb.numel()] = wb; wb = wire_buf[s % NCTX] = nb
+        pad = wb[: max(width, 1)].to(xdev)
         out = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
         dist.gather(pad, out, dst=0)
         if rank == 0 and keep:
@@ -242,7 +254,7 @@ def main():
         sync()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device=xdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, k2

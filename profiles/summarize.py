@@ -42,12 +42,14 @@ def per_kernel(rows):
 
 
 def kernel_sources_sha():
+    # the sources of the dominant kernel (mtr_k_reads) and the flags it is built with; the host side of the library
+    # (mtr_abi.hip) and the staged mode's kernels (k3_staged.hip.inc) are not part of it
     h = hashlib.sha256()
     d = os.path.join(ROOT, "mtr_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".inc", ".hip", ".h")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in ("device_util.hip.inc", "dp_wrap.hip.inc", "k1_ranges.hip.inc", "k2_units.hip.inc", "mtr_common.h", "min_missing_table.h"):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "mtr_amd", "build.py"), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -133,3 +133,26 @@ def test_pure_repeat_with_unit_250_to_256_as_longest_read(unit_len):
             del os.environ["MTR_SPLIT"]
         assert [[tuple(r) for r in g] for g in got] == want, split
     assert any(r[3] == unit_len for r in want[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_strong_scaling_gathers_the_oracles_record_stream():
+    """BASELINE config 4 as bench.py measures it with N ranks: 100 000 reads in contiguous blocks, every rank's record tables
+    (wire form, exported on the device) gathered to rank 0; the sha256 of the gathered stream must be the CPU oracle's
+    (tests/golden/c4_100k_wire.json).  With one GPU visible two ranks share it and the exchange goes through gloo
+    (MTR_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device); the driver's runs use RCCL, one GPU per rank."""
+    import json
+    import torch
+    n = torch.cuda.device_count()
+    world = n if n > 1 else 2
+    env = {k: v for k, v in os.environ.items() if k not in ("MTR_LIB", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    if n == 1:
+        env["MTR_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--strong", "c4", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, env=env, timeout=800, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == world and line["scaling"] == "strong"
+    st = line["strong"]
+    assert st["ranks_seen"] == world and sum(st["reads_per_rank"]) == 100000 and st["matches_oracle"] is True, st

@@ -52,9 +52,11 @@ int main(int argc, char **argv)
     for (mtrh_result *x; (x = mtrh_run_next(run)) != NULL; ) mtrh_printer_push(pr, x);
     double t_chain = 0;
     const int status = mtrh_printer_finish(pr, &t_chain);
+    mtrh_stamp("everything printed");
     double t_wait = 0, t_submit = 0, t_fetch = 0, t_kernel = 0; long long queries = 0;
     mtrh_run_timing(run, &t_wait, &t_submit, &t_fetch, &t_kernel, &queries);
     mtrh_run_stop(run);
+    mtrh_stamp("run stopped");
     if (getenv("MTR_HOST_TIMING"))                /* development aid: phase times on stderr */
         fprintf(stderr, "[host] waiting for the parser threads %.3f s, upload+launch %.3f s, waiting for the device + fetch %.3f s (kernels %.3f s), chain+print %.3f s, all %.3f s\n",
                 t_wait, t_submit, t_fetch, t_kernel, t_chain, now() - t_all);

@@ -124,6 +124,7 @@ int   mtrh_run_round_of(const mtrh_run *r, int chunk);
 /* next finished result of this rank in output order (blocks); NULL at the end */
 mtrh_result *mtrh_run_next(mtrh_run *r);
 void  mtrh_run_timing(const mtrh_run *r, double *t_parse_wait, double *t_submit, double *t_fetch, double *t_kernel, long long *queries);
+void  mtrh_stamp(const char *what);           /* development aid: with MTR_HOST_TIMING set, a line on stderr with the time since the first stamp */
 void  mtrh_run_stop(mtrh_run *r);
 /* all results this rank produces for `round`, serialised one after the other (malloc'ed; free() it) */
 uint8_t *mtrh_run_round_blob(mtrh_run *r, int round, size_t *bytes);

@@ -37,6 +37,13 @@ struct mtrh_run {
 };
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+/* development aid (MTR_HOST_TIMING): a line on stderr with the time since the first stamp */
+void mtrh_stamp(const char *what)
+{
+    static int on = -1; static double t_first;
+    if (on < 0) { on = getenv("MTR_HOST_TIMING") ? 1 : 0; t_first = now_s(); }
+    if (on) fprintf(stderr, "[host +%.3f s] %s\n", now_s() - t_first, what);
+}
 
 /* ---- plan ------------------------------------------------------------------------------------------------------------- */
 static int cmp_size_desc(const void *a, const void *b)
@@ -203,6 +210,7 @@ static void finish_batch(mtrh_run *r, mtr_ctx *ctx, mtrh_result *x)
     const double t0 = now_s();
     const mtrh_batch *b = x->batch;
     mtr_status st = r->eng.wait(ctx);
+    { static int first = 1; if (first) { first = 0; mtrh_stamp("first batch: device done"); } }
     int n_report = b->n;
     if (st == MTR_ERR_DP_TOO_LARGE) {
         /* like the reference (wrap_around_DP.c:96-99): everything before the failing read is reported, then the message */
@@ -292,6 +300,7 @@ static void *device_main(void *arg)
             mtr_status st = MTR_OK;
             if (!*pc) {
                 st = r->eng.create(r->o.device, r->o.manhattan, r->o.min_match_ratio, pc);
+                mtrh_stamp(k == 0 ? "first device context created" : "second device context created");
                 if (st != MTR_OK) {
                     char m[256];
                     snprintf(m, sizeof m, "fatal error: no usable HIP device (mtr_create returned %d); this build has no CPU path", (int)st);
@@ -307,6 +316,7 @@ static void *device_main(void *arg)
             if (!r->o.print_alignment && !r->o.file_order) { free(b->codes); b->codes = NULL; }   /* only -a rows and -B need the byte codes from here on */
             free(b->packed); b->packed = NULL;
             pthread_mutex_lock(&r->mu); r->t_submit += now_s() - t0; pthread_mutex_unlock(&r->mu);
+            if (k < 2) mtrh_stamp(k == 0 ? "first batch uploaded and launched" : "second batch uploaded and launched");
             if (prev) { finish_batch(r, prev_ctx, prev); prev = NULL; }       /* like the reference: everything before a failure is reported first */
             if (dead) {
                 x->counts = (int32_t *)calloc(1, sizeof(int32_t));
@@ -320,8 +330,10 @@ static void *device_main(void *arg)
         }
     }
     if (prev) finish_batch(r, prev_ctx, prev);
+    mtrh_stamp("last batch fetched");
     if (fs) r->eng.fs_destroy(fs);
     for (int t = 0; t < 2; t++) if (ctxs[t]) r->eng.destroy(ctxs[t]);
+    mtrh_stamp("device contexts destroyed");
     free(file_ended); free(dead_msg);
     pthread_mutex_lock(&r->mu);
     r->device_done = 1;
@@ -338,10 +350,12 @@ mtrh_run *mtrh_run_start(const mtrh_opts *o, const char *const *paths, int n_pat
     r->o = *o;
     if (r->o.world < 1) { r->o.world = 1; r->o.rank = 0; }
     char err[512];
+    mtrh_stamp("start");
     if (mtrh_engine_load(&r->eng, o->engine_lib, err, sizeof err) != 0) { fprintf(stderr, "fatal error: %s\n", err); free(r); return NULL; }
     r->n_files = n_paths; r->files = (mtrh_file *)calloc((size_t)n_paths, sizeof(mtrh_file));
     for (int f = 0; f < n_paths; f++)
         if (mtrh_file_open(&r->files[f], paths[f]) != 0) { for (int g = 0; g < f; g++) mtrh_file_close(&r->files[g]); free(r->files); free(r); return NULL; }
+    mtrh_stamp("engine library loaded, files mapped");
     plan(r);
     /* what this rank parses: its own chunks; with -B every chunk up to its last one (the state needs the reads before) */
     r->list = (int *)malloc(sizeof(int) * ((size_t)r->n_chunks + 1));

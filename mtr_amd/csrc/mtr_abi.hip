@@ -111,6 +111,9 @@ struct mtr_ctx {
 // contexts on it (a second context costs no generation and no upload).
 static std::mutex g_mt_mu;
 static struct { uint8_t *d = nullptr; int refs = 0; } g_mt[64];
+// live contexts per device: a caller that holds several keeps several launches in flight (the mode policy asks, use_staged)
+static std::mutex g_nctx_mu;
+static int g_nctx[64];
 static std::vector<uint8_t> g_mt_host;
 static const std::vector<uint8_t> &mt_host()
 {   // callers hold g_mt_mu
@@ -303,6 +306,7 @@ extern "C" mtr_status mtr_create(int device, int manhattan, float min_match_rati
         if (ok) { ctx->d_mt = g_mt[device].d; g_mt[device].refs++; }
     } else ok = false;
     if (!ok) { mtr_destroy(ctx); return MTR_ERR_NO_DEVICE; }
+    { std::lock_guard<std::mutex> g(g_nctx_mu); if (device >= 0 && device < 64) g_nctx[device]++; }
     *out = ctx;
     return MTR_OK;
 }
@@ -311,6 +315,8 @@ extern "C" void mtr_destroy(mtr_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->pending) { (void)hipStreamSynchronize(ctx->stream); ctx->pending = false; }
+    { std::lock_guard<std::mutex> g(g_nctx_mu); if (ctx->device >= 0 && ctx->device < 64 && g_nctx[ctx->device] > 0) g_nctx[ctx->device]--; }
     release_batch_buffers(ctx);
     if (ctx->d_mt) {
         std::lock_guard<std::mutex> lk(g_mt_mu);
@@ -698,6 +704,11 @@ static int staged_lane_umax()
     const int v = e ? atoi(e) : 0;
     return v < 0 ? 0 : (v > ST_UMAX ? ST_UMAX : v);
 }
+static int live_contexts(int device)
+{
+    std::lock_guard<std::mutex> g(g_nctx_mu);
+    return device >= 0 && device < 64 ? g_nctx[device] : 1;
+}
 static bool use_staged(const mtr_ctx *ctx)
 {
     const char *e = getenv("MTR_STAGED");
@@ -709,7 +720,17 @@ static bool use_staged(const mtr_ctx *ctx)
     // the range-parallel mode up to 4 096 (use_split), the per-read kernel above.
     const char *m = getenv("MTR_STAGED_MAX_READS");
     const long max_reads = m ? atol(m) : 3000;
-    return ctx->n_reads <= max_reads;
+    if (ctx->n_reads <= max_reads) return true;
+    // Larger batches [measured after the work queues got sub-queues, 10 000 reads of 2 kb]: a launch that has the chip to itself
+    // takes 68-69 ms staged and 77-78 ms in the per-read kernel (no tail of slow reads); two contexts that keep two launches in
+    // flight run at 59.5 ms a step staged and 53.3 ms with the per-read kernel (the chain executes 10 % more instructions, and both
+    // are bound by instruction issue).  And the two do not mix: a per-read kernel launched behind a staged chain takes every
+    // wavefront slot as the chain's current kernel drains and holds them until it ends - it finishes first, the chain waits.
+    // So: staged while this is the device's only context; a caller that holds two (the command line on files of more than one
+    // batch, bench.py) pipelines and gets the per-read kernel throughout.
+    const char *l = getenv("MTR_STAGED_MAX_READS_LONE");
+    const long max_lone = l ? atol(l) : 12000;
+    return ctx->n_reads <= max_lone && live_contexts(ctx->device) <= 1;
 }
 
 static mtr_status launch_staged(mtr_ctx *ctx)
@@ -740,7 +761,9 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     HIPCHK(ensure_dev(ctx, ctx->d_st_dpbin, (size_t)s.dp_cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_dprank, (size_t)s.dp_cap * 4));
     HIPCHK(ensure_dev(ctx, ctx->d_st_sorted, (size_t)s.sorted_cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_classwave, 8 * 4));
     HIPCHK(ensure_dev(ctx, ctx->d_st_cand, (size_t)s.cand_cap * sizeof(DevRecord))); HIPCHK(ensure_dev(ctx, ctx->d_st_flag, (size_t)std::max<int64_t>(ctx->total_rcap, 1) * 4));
-    HIPCHK(ensure_dev(ctx, ctx->d_st_scalars, 64 * 8));
+    // device scalars, each on a 256-byte line of its own (same-line atomics complete one after the other), then the work queues
+    const size_t st_scalar_bytes = 16 * 256 + (size_t)ST_N_QUEUES * WQ_WORDS * 4;
+    HIPCHK(ensure_dev(ctx, ctx->d_st_scalars, st_scalar_bytes));
     HIPCHK(ensure_dev(ctx, ctx->d_st_wv, (size_t)s.dp_cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_res, (size_t)s.dp_cap * 16 * 4));
     s.lane_umax = staged_lane_umax(); s.wv_items = ctx->d_st_wv; s.dp_res = ctx->d_st_res;
     s.item_cap = (int32_t)std::min<int64_t>(0x7fffff00, ctx->total_rcap);
@@ -754,16 +777,16 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     HIPCHK(ensure_dev(ctx, ctx->d_st_rev, (size_t)s.rev_cap * 8));
     s.rev_items = (long long *)ctx->d_st_rev;
     unsigned long long *sc = ctx->d_st_scalars;
-    s.item_off = ctx->d_item_off; s.n_items = (int32_t *)(sc + 0);
-    s.arena = ctx->d_st_arena; s.arena_cur = sc + 1;
-    s.kc_items = (long long *)ctx->d_st_kc; s.n_kc = (unsigned *)(sc + 2);
-    s.dp = ctx->d_st_dp; s.n_dp = (unsigned *)(sc + 3);
-    s.codes = ctx->d_st_codes; s.codes_cur = sc + 4;
+    s.item_off = ctx->d_item_off; s.n_items = (int32_t *)(sc + 0 * 32);
+    s.arena = ctx->d_st_arena; s.arena_cur = sc + 1 * 32;
+    s.kc_items = (long long *)ctx->d_st_kc; s.n_kc = (unsigned *)(sc + 2 * 32);
+    s.dp = ctx->d_st_dp; s.n_dp = (unsigned *)(sc + 3 * 32);
+    s.codes = ctx->d_st_codes; s.codes_cur = sc + 4 * 32;
     s.bin_count = ctx->d_st_bincnt; s.dp_bin = ctx->d_st_dpbin; s.dp_rank = ctx->d_st_dprank;
     s.bin_start = ctx->d_st_binstart; s.sorted = ctx->d_st_sorted; s.class_wave = ctx->d_st_classwave;
-    s.cand = ctx->d_st_cand; s.n_cand = (unsigned *)(sc + 5); s.cand_flag = ctx->d_st_flag;
-    s.n_wv = (unsigned *)(sc + 6); s.n_cont = (unsigned *)(sc + 7); s.n_rev = (unsigned *)(sc + 16);
-    s.work = (unsigned *)(sc + 8);
+    s.cand = ctx->d_st_cand; s.n_cand = (unsigned *)(sc + 5 * 32); s.cand_flag = ctx->d_st_flag;
+    s.n_wv = (unsigned *)(sc + 6 * 32); s.n_cont = (unsigned *)(sc + 7 * 32); s.n_rev = (unsigned *)(sc + 8 * 32);
+    s.work = (unsigned *)(sc + 16 * 32);
     K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
     // few reads: the range finder as one wavefront per (read, pass) over per-READ scratch (launch_k1_parts), as in the
     // range-parallel mode; the unit kernels then take their per-wavefront scratch behind it
@@ -780,7 +803,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     K1Args a1{}; k1_args(ctx, a1, per_wave);
     K2Args a{}; k2_args(ctx, a, per_wave);
     HIPCHK(hipMemsetAsync(ctx->d_trace_n, 0, sizeof(unsigned), ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->d_st_scalars, 0, 64 * 8, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_st_scalars, 0, st_scalar_bytes, ctx->stream));
     if (s.lane_umax > 0) {
         HIPCHK(hipMemsetAsync(ctx->d_st_bincnt, 0, (size_t)ST_NBINS * 4, ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->d_st_sorted, 0xFF, (size_t)s.sorted_cap * 4, ctx->stream));
@@ -880,6 +903,7 @@ extern "C" mtr_status mtr_run_resident_async(mtr_ctx *ctx)
     HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
     ctx->last_staged = use_staged(ctx);
     ctx->last_split = !ctx->last_staged && use_split(ctx);
+    DBG("launch of %d reads: %s", ctx->n_reads, ctx->last_staged ? "staged chain" : ctx->last_split ? "range-parallel" : "per-read kernel");
     mtr_status s = ctx->last_staged ? launch_staged(ctx) : ctx->last_split ? launch_split(ctx) : launch_reads(ctx); if (s != MTR_OK) return s;
     ctx->pending = true;
     return MTR_OK;
@@ -898,10 +922,10 @@ extern "C" mtr_status mtr_wait(mtr_ctx *ctx)
     HIPCHK(copy_sync(ctx, ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
     mtr_status st = check_status(ctx);
     if (ctx->last_staged && dbg()) {
-        unsigned long long sc[16]; int32_t cw[8];
+        unsigned long long sc[8 * 32]; int32_t cw[8];
         if (copy_sync(ctx, sc, ctx->d_st_scalars, sizeof sc, hipMemcpyDeviceToHost) == hipSuccess && copy_sync(ctx, cw, ctx->d_st_classwave, sizeof cw, hipMemcpyDeviceToHost) == hipSuccess)
             DBG("staged: items %d, ranges with a block %u (+ %u per-k work items), DP items %u (%u one wavefront each), candidate arena %.1f MB, cells %.2f GB, records parked %u; wavefronts per unit-length class %d %d %d %d",
-                (int)(int32_t)sc[0], (unsigned)sc[2], (unsigned)sc[7], (unsigned)sc[3], (unsigned)sc[6], (double)sc[1] / 1e6, (double)sc[4] / 1e9, (unsigned)sc[5], cw[1] - cw[0], cw[2] - cw[1], cw[3] - cw[2], cw[4] - cw[3]);
+                (int)(int32_t)sc[0], (unsigned)sc[2 * 32], (unsigned)sc[7 * 32], (unsigned)sc[3 * 32], (unsigned)sc[6 * 32], (double)sc[1 * 32] / 1e6, (double)sc[4 * 32] / 1e9, (unsigned)sc[5 * 32], cw[1] - cw[0], cw[2] - cw[1], cw[3] - cw[2], cw[4] - cw[3]);
     }
     if (st == MTR_ERR_OVERFLOW && ctx->last_staged) {
         // the batch outgrew a buffer of the staged mode: the per-read kernel takes it (same results)

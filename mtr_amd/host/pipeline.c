@@ -301,6 +301,12 @@ static void *device_main(void *arg)
             if (!*pc) {
                 st = r->eng.create(r->o.device, r->o.manhattan, r->o.min_match_ratio, pc);
                 mtrh_stamp(k == 0 ? "first device context created" : "second device context created");
+                /* more input behind this batch: the second context now, so that the engine knows from the first launch on that
+                 * launches will overlap (it picks its kernel mode by that, mtr_abi.hip use_staged) */
+                if (st == MTR_OK && k == 0 && !ctxs[1] && (nx != NULL || idx + 1 < r->n_list)) {
+                    st = r->eng.create(r->o.device, r->o.manhattan, r->o.min_match_ratio, &ctxs[1]);
+                    mtrh_stamp("second device context created");
+                }
                 if (st != MTR_OK) {
                     char m[256];
                     snprintf(m, sizeof m, "fatal error: no usable HIP device (mtr_create returned %d); this build has no CPU path", (int)st);

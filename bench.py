@@ -242,6 +242,8 @@ def main():
 
     def timed(steps, fetch=True):
         k2 = []
+        for e in engs:                                  # the steps of the timed region overlap (two contexts): say so, as the
+            e.set_overlapped(NCTX > 1)                  # command-line driver does; the warm-up steps run one at a time
         sync()
         t0 = time.perf_counter()
         depth = NCTX - 1                                # steps enqueued ahead of the one being finished
@@ -253,6 +255,8 @@ def main():
             k2.append(finish(s, fetch, keep=(s == steps - 1))["k2_units"])
         sync()
         dt = time.perf_counter() - t0
+        for e in engs:
+            e.set_overlapped(False)
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=xdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -260,9 +264,11 @@ def main():
         return dt, k2
 
     sync_k2 = []
+    lone_mode = None
     for w in range(a.warmup):                           # warm-up steps run one at a time (un-overlapped kernel times)
         engs[w % NCTX].run_async()
         sync_k2.append(finish(w)["k2_units"])
+        lone_mode = engs[w % NCTX].last_mode()
     dt, k2_ms = timed(a.steps, fetch=True)
     dt_kernel = None
     if world == 1:
@@ -308,7 +314,9 @@ def main():
             "ms_per_read": dt / a.steps * 1e3 / max(n_job, 1),
             "kernels_ms": {"mtr_k_reads": float(np.mean(k2_ms)),
                            "note": "HIP-event durations over the timed region; consecutive steps overlap on the GPU, so a launch shares the chip with its neighbour"},
-            "kernels_ms_alone": {"mtr_k_reads": float(np.mean(sync_k2)) if sync_k2 else None},
+            "kernels_ms_alone": {"launch": float(np.mean(sync_k2)) if sync_k2 else None, "mode": lone_mode,
+                                 "note": "a launch that has the GPU to itself (the warm-up steps); the engine picks the mode, mtr_set_overlapped_launches"},
+            "kernels_mode_timed": eng.last_mode(),
             "work_per_launch": {k: cnt[k] for k in ("dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_dp_cells", "memo_hits", "memo_cells",
                                                     "kmer_tables", "tables_skipped", "kmer_lookups", "ranges_executed", "records", "traceback_steps")},
             "roofline": {"bound": "hbm", "kernel": "mtr_k_reads", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -101,6 +101,12 @@ mtr_status mtr_run_resident(mtr_ctx *ctx);
  * one batch with the start of the next (bench.py pipelines its steps this way). */
 mtr_status mtr_run_resident_async(mtr_ctx *ctx);
 mtr_status mtr_wait(mtr_ctx *ctx);
+/* The library has two ways to run a batch of more than a few thousand reads (same records): a chain of kernels over the
+ * whole batch, fastest when the launch has the GPU to itself, and one kernel with a wavefront per read, fastest when the
+ * launches of several contexts overlap.  By default a launch decides by whether another context of the device has a launch
+ * that has not been waited for.  A host pipeline that WILL overlap launches says so here (1) before its first one, so that
+ * the first launch already is of the overlapping kind; 0 restores the default. */
+mtr_status mtr_set_overlapped_launches(mtr_ctx *ctx, int32_t overlapped);
 mtr_status mtr_fetch_results(mtr_ctx *ctx, mtr_record **out_records, int32_t **out_counts, int64_t *out_total);
 /* A failed run (mtr_wait returned an error) is remembered: fetch / export / alignments of that batch return the same
  * status instead of partial records.  After MTR_ERR_DP_TOO_LARGE the reads BEFORE the failing one (input order) are

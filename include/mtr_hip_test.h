@@ -25,6 +25,10 @@ mtr_status mtr_test_wrap_dp(mtr_ctx *ctx, int32_t n_tasks, const int32_t *read_i
                             const int32_t *query_end, const uint8_t *units, const int32_t *unit_off,
                             const int32_t *gain, const int32_t *mismatch, const int32_t *indel, int32_t *out8);
 
+/* How the last launch ran: 0 = one kernel, a wavefront per read; 1 = range-parallel; 2 = the staged chain of kernels.
+ * (The records do not depend on it; tests pin the policy of mtr_hip.h's mtr_set_overlapped_launches with it.) */
+int32_t mtr_test_last_mode(const mtr_ctx *ctx);
+
 /* Event trace of the last run (debug aid for parity work): enable before mtr_run_resident.
  * Each event is 16 int32: [0]=type (2 search, 3 DP, 4 polish, 5 revise, 6 record), [1]=read index,
  * then type-specific fields (the trace_ev() calls in mtr_amd/csrc/k2_units.hip.inc). */

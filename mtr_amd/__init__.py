@@ -28,8 +28,8 @@ COUNTER_NAMES = ["dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_d
                  "walk_calls", "walk_closed", "cyc_walk_fast", "spare43", "spare44", "spare45", "spare46", "spare47"]
 EXPORTS = ["mtr_create", "mtr_destroy", "mtr_last_error", "mtr_abi_version", "mtr_process_batch", "mtr_free_results",
            "mtr_upload_batch", "mtr_run_resident", "mtr_fetch_results", "mtr_get_kernel_times", "mtr_get_counters",
-           "mtr_test_ranges", "mtr_test_wrap_dp", "mtr_set_trace", "mtr_get_trace", "mtr_export_records_device",
-           "mtr_run_resident_async", "mtr_wait", "mtr_alignments",
+           "mtr_test_ranges", "mtr_test_wrap_dp", "mtr_test_last_mode", "mtr_set_trace", "mtr_get_trace", "mtr_export_records_device",
+           "mtr_run_resident_async", "mtr_wait", "mtr_set_overlapped_launches", "mtr_alignments",
            "mtr_file_state_create", "mtr_file_state_destroy", "mtr_upload_batch_in_file", "mtr_file_state_skip",
            "mtr_get_bases_after_read", "mtr_upload_batch_packed", "mtr_fetch_results_packed", "mtr_export_packed_device",
            "mtr_unpack_records", "mtr_pack_records", "mtr_get_first_failed_read"]
@@ -138,6 +138,10 @@ def load_library(path: str = LIB_PATH):
     lib.mtr_run_resident_async.restype = C.c_int
     lib.mtr_wait.argtypes = [C.c_void_p]
     lib.mtr_wait.restype = C.c_int
+    lib.mtr_test_last_mode.argtypes = [C.c_void_p]
+    lib.mtr_test_last_mode.restype = C.c_int32
+    lib.mtr_set_overlapped_launches.argtypes = [C.c_void_p, C.c_int32]
+    lib.mtr_set_overlapped_launches.restype = C.c_int
     lib.mtr_fetch_results.argtypes = [C.c_void_p, P(P(CRecord)), P(P(C.c_int32)), P(C.c_int64)]
     lib.mtr_fetch_results.restype = C.c_int
     lib.mtr_get_kernel_times.argtypes = [C.c_void_p, P(CKernelTime), C.c_int32]
@@ -239,6 +243,14 @@ class Engine:
 
     def wait(self):
         self._check(self.lib.mtr_wait(self.h), "mtr_wait")
+
+    def last_mode(self) -> str:
+        """how the last launch ran (mtr_test_last_mode)"""
+        return {0: "per-read kernel", 1: "range-parallel", 2: "staged chain"}.get(int(self.lib.mtr_test_last_mode(self.h)), "?")
+
+    def set_overlapped(self, on: bool = True):
+        """tell the engine that launches of several contexts will overlap on this device (mtr_set_overlapped_launches)"""
+        self._check(self.lib.mtr_set_overlapped_launches(self.h, 1 if on else 0), "mtr_set_overlapped_launches")
 
     def fetch(self) -> List[List[Record]]:
         recs = C.POINTER(CRecord)()

@@ -96,6 +96,7 @@ struct mtr_ctx {
     mtr_kernel_time kt[2] = { { 0, 0 }, { 0, 0 } };
     unsigned long long counters[CNT_N] = { 0 };
     bool ran = false, pending = false;
+    bool overlapped = false;           // mtr_set_overlapped_launches
     mtr_status run_status = MTR_OK;                    // of the last run: latched until the next upload
     int32_t first_failed = -1; int32_t *d_fail_read = nullptr;   // first read (input order) whose DP exceeded WrapDPsize
     // wire-form fetch: per-read byte sizes / offsets on the device, pinned staging on the host (grow-only)
@@ -111,9 +112,14 @@ struct mtr_ctx {
 // contexts on it (a second context costs no generation and no upload).
 static std::mutex g_mt_mu;
 static struct { uint8_t *d = nullptr; int refs = 0; } g_mt[64];
-// live contexts per device: a caller that holds several keeps several launches in flight (the mode policy asks, use_staged)
-static std::mutex g_nctx_mu;
-static int g_nctx[64];
+// launches the host has not waited for, per device (the mode policy asks whether launches overlap, use_staged)
+static std::mutex g_pending_mu;
+static int g_pending[64];
+static void pending_add(int device, int d)
+{
+    std::lock_guard<std::mutex> g(g_pending_mu);
+    if (device >= 0 && device < 64) { g_pending[device] += d; if (g_pending[device] < 0) g_pending[device] = 0; }
+}
 static std::vector<uint8_t> g_mt_host;
 static const std::vector<uint8_t> &mt_host()
 {   // callers hold g_mt_mu
@@ -306,7 +312,6 @@ extern "C" mtr_status mtr_create(int device, int manhattan, float min_match_rati
         if (ok) { ctx->d_mt = g_mt[device].d; g_mt[device].refs++; }
     } else ok = false;
     if (!ok) { mtr_destroy(ctx); return MTR_ERR_NO_DEVICE; }
-    { std::lock_guard<std::mutex> g(g_nctx_mu); if (device >= 0 && device < 64) g_nctx[device]++; }
     *out = ctx;
     return MTR_OK;
 }
@@ -315,8 +320,7 @@ extern "C" void mtr_destroy(mtr_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->pending) { (void)hipStreamSynchronize(ctx->stream); ctx->pending = false; }
-    { std::lock_guard<std::mutex> g(g_nctx_mu); if (ctx->device >= 0 && ctx->device < 64 && g_nctx[ctx->device] > 0) g_nctx[ctx->device]--; }
+    if (ctx->pending) { (void)hipStreamSynchronize(ctx->stream); ctx->pending = false; pending_add(ctx->device, -1); }
     release_batch_buffers(ctx);
     if (ctx->d_mt) {
         std::lock_guard<std::mutex> lk(g_mt_mu);
@@ -704,10 +708,10 @@ static int staged_lane_umax()
     const int v = e ? atoi(e) : 0;
     return v < 0 ? 0 : (v > ST_UMAX ? ST_UMAX : v);
 }
-static int live_contexts(int device)
+static int pending_launches(int device)
 {
-    std::lock_guard<std::mutex> g(g_nctx_mu);
-    return device >= 0 && device < 64 ? g_nctx[device] : 1;
+    std::lock_guard<std::mutex> g(g_pending_mu);
+    return device >= 0 && device < 64 ? g_pending[device] : 0;
 }
 static bool use_staged(const mtr_ctx *ctx)
 {
@@ -726,11 +730,11 @@ static bool use_staged(const mtr_ctx *ctx)
     // flight run at 59.5 ms a step staged and 53.3 ms with the per-read kernel (the chain executes 10 % more instructions, and both
     // are bound by instruction issue).  And the two do not mix: a per-read kernel launched behind a staged chain takes every
     // wavefront slot as the chain's current kernel drains and holds them until it ends - it finishes first, the chain waits.
-    // So: staged while this is the device's only context; a caller that holds two (the command line on files of more than one
-    // batch, bench.py) pipelines and gets the per-read kernel throughout.
+    // So: staged unless launches overlap - the caller has said so (mtr_set_overlapped_launches: the command line on files of
+    // more than one batch, bench.py's timed steps), or another context's launch is waiting to be collected right now.
     const char *l = getenv("MTR_STAGED_MAX_READS_LONE");
     const long max_lone = l ? atol(l) : 12000;
-    return ctx->n_reads <= max_lone && live_contexts(ctx->device) <= 1;
+    return ctx->n_reads <= max_lone && !ctx->overlapped && pending_launches(ctx->device) == 0;
 }
 
 static mtr_status launch_staged(mtr_ctx *ctx)
@@ -906,6 +910,16 @@ extern "C" mtr_status mtr_run_resident_async(mtr_ctx *ctx)
     DBG("launch of %d reads: %s", ctx->n_reads, ctx->last_staged ? "staged chain" : ctx->last_split ? "range-parallel" : "per-read kernel");
     mtr_status s = ctx->last_staged ? launch_staged(ctx) : ctx->last_split ? launch_split(ctx) : launch_reads(ctx); if (s != MTR_OK) return s;
     ctx->pending = true;
+    pending_add(ctx->device, 1);
+    return MTR_OK;
+}
+
+extern "C" int32_t mtr_test_last_mode(const mtr_ctx *ctx) { return !ctx ? -1 : ctx->last_staged ? 2 : ctx->last_split ? 1 : 0; }
+
+extern "C" mtr_status mtr_set_overlapped_launches(mtr_ctx *ctx, int32_t overlapped)
+{
+    if (!ctx) return MTR_ERR_BAD_ARG;
+    ctx->overlapped = overlapped != 0;
     return MTR_OK;
 }
 
@@ -914,6 +928,7 @@ extern "C" mtr_status mtr_wait(mtr_ctx *ctx)
     if (!ctx) return MTR_ERR_BAD_ARG;
     if (!ctx->pending) return ctx->run_status;
     HIPCHK(hipSetDevice(ctx->device));
+    pending_add(ctx->device, -1);
     ctx->pending = false; ctx->ran = false; ctx->run_status = MTR_ERR_HIP;   // until everything below succeeded
     HIPCHK(hipStreamSynchronize(ctx->stream));
     float ms = 0;

@@ -34,6 +34,7 @@ struct mtrh_run {
     int n_parsers; pthread_t parsers[16], device;
     mtrh_result *queue[RESULT_QUEUE]; int q_head, q_n, device_done, stopping;
     double t_parse_wait, t_submit, t_fetch, t_kernel; long long queries;
+    int overlap;                                   /* more than one device batch: launches of the two contexts overlap */
 };
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
@@ -301,11 +302,10 @@ static void *device_main(void *arg)
             if (!*pc) {
                 st = r->eng.create(r->o.device, r->o.manhattan, r->o.min_match_ratio, pc);
                 mtrh_stamp(k == 0 ? "first device context created" : "second device context created");
-                /* more input behind this batch: the second context now, so that the engine knows from the first launch on that
-                 * launches will overlap (it picks its kernel mode by that, mtr_abi.hip use_staged) */
-                if (st == MTR_OK && k == 0 && !ctxs[1] && (nx != NULL || idx + 1 < r->n_list)) {
-                    st = r->eng.create(r->o.device, r->o.manhattan, r->o.min_match_ratio, &ctxs[1]);
-                    mtrh_stamp("second device context created");
+                /* more input behind this batch: launches will overlap (the engine picks its kernel mode by that, mtr_hip.h) */
+                if (st == MTR_OK && (r->overlap || nx != NULL || idx + 1 < r->n_list)) {
+                    r->overlap = 1;
+                    if (r->eng.set_overlapped) (void)r->eng.set_overlapped(*pc, 1);
                 }
                 if (st != MTR_OK) {
                     char m[256];

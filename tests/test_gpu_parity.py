@@ -290,6 +290,34 @@ def test_kernel_modes_match_the_oracle(monkeypatch, oracle, mode):
     e.close()
 
 
+def test_mode_policy_lone_and_overlapping_launches(monkeypatch):
+    """include/mtr_hip.h, mtr_set_overlapped_launches: a batch of more than a few thousand reads runs as the staged chain while
+    its launch has the GPU to itself, and in the per-read kernel when launches overlap - because another context's launch is
+    waiting to be collected, or because the caller has said so.  The records are the same in every case."""
+    for k in ("MTR_STAGED", "MTR_SPLIT", "MTR_STAGED_MAX_READS", "MTR_STAGED_MAX_READS_LONE", "MTR_LPT"):
+        monkeypatch.delenv(k, raising=False)
+    reads = [c for _, c in synth.make_reads("headline2k", 3600, 17)]
+    a, b = mtr_amd.Engine(), mtr_amd.Engine()
+    a.upload(reads); b.upload(reads)
+    a.run()
+    assert a.last_mode() == "staged chain"
+    lone = [[tuple(r) for r in g] for g in a.fetch()]
+    a.run_async(); b.run_async()                                   # b is launched while a's launch is pending
+    a.wait(); b.wait()
+    assert a.last_mode() == "staged chain" and b.last_mode() != "staged chain"        # (range-parallel up to 4 096 reads, per-read kernel above)
+    assert [[tuple(r) for r in g] for g in b.fetch()] == lone
+    a.set_overlapped(True)
+    a.run()
+    assert a.last_mode() != "staged chain"
+    assert [[tuple(r) for r in g] for g in a.fetch()] == lone
+    a.set_overlapped(False)
+    small = reads[:500]
+    a.upload(small); a.set_overlapped(True); a.run()
+    assert a.last_mode() == "staged chain"                          # small batches: the chain either way
+    assert [[tuple(r) for r in g] for g in a.fetch()] == lone[:500]
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("mode", ["range_parallel", "staged", "staged_lanes128"])
 def test_kernel_modes_golden(monkeypatch, mode):
     for k, v in MODES[mode].items():

@@ -713,6 +713,7 @@ static int pending_launches(int device)
     std::lock_guard<std::mutex> g(g_pending_mu);
     return device >= 0 && device < 64 ? g_pending[device] : 0;
 }
+static unsigned st_sum(const unsigned long long *cls) { unsigned t = 0; for (int c = 0; c < ST_NCLS; c++) t += (unsigned)cls[c * 32]; return t; }
 static bool use_staged(const mtr_ctx *ctx)
 {
     const char *e = getenv("MTR_STAGED");
@@ -766,19 +767,19 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     HIPCHK(ensure_dev(ctx, ctx->d_st_sorted, (size_t)s.sorted_cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_classwave, 8 * 4));
     HIPCHK(ensure_dev(ctx, ctx->d_st_cand, (size_t)s.cand_cap * sizeof(DevRecord))); HIPCHK(ensure_dev(ctx, ctx->d_st_flag, (size_t)std::max<int64_t>(ctx->total_rcap, 1) * 4));
     // device scalars, each on a 256-byte line of its own (same-line atomics complete one after the other), then the work queues
-    const size_t st_scalar_bytes = 16 * 256 + (size_t)ST_N_QUEUES * WQ_WORDS * 4;
+    const size_t st_scalar_bytes = 64 * 256 + (size_t)ST_N_QUEUES * WQ_WORDS * 4;
     HIPCHK(ensure_dev(ctx, ctx->d_st_scalars, st_scalar_bytes));
-    HIPCHK(ensure_dev(ctx, ctx->d_st_wv, (size_t)s.dp_cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_res, (size_t)s.dp_cap * 16 * 4));
+    HIPCHK(ensure_dev(ctx, ctx->d_st_wv, (size_t)ST_NCLS * (size_t)s.dp_cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_res, (size_t)s.dp_cap * 16 * 4));
     s.lane_umax = staged_lane_umax(); s.wv_items = ctx->d_st_wv; s.dp_res = ctx->d_st_res;
     s.item_cap = (int32_t)std::min<int64_t>(0x7fffff00, ctx->total_rcap);
     HIPCHK(ensure_dev(ctx, ctx->d_st_items, (size_t)std::max(s.item_cap, 1) * sizeof(int4)));
     s.item_tab = ctx->d_st_items;
     s.cont_cap = (int32_t)std::min<int64_t>(0x7fffff00, 2 * (int64_t)s.kc_cap);
-    HIPCHK(ensure_dev(ctx, ctx->d_st_cont, (size_t)s.cont_cap * sizeof(int4)));
+    HIPCHK(ensure_dev(ctx, ctx->d_st_cont, (size_t)ST_NCLS * (size_t)s.cont_cap * sizeof(int4)));
     s.cont = ctx->d_st_cont;
     s.k_first = getenv("MTR_STAGED_K_FIRST") ? std::max(1, atoi(getenv("MTR_STAGED_K_FIRST"))) : 3;
     s.rev_cap = s.kc_cap;
-    HIPCHK(ensure_dev(ctx, ctx->d_st_rev, (size_t)s.rev_cap * 8));
+    HIPCHK(ensure_dev(ctx, ctx->d_st_rev, (size_t)ST_NCLS * (size_t)s.rev_cap * 8));
     s.rev_items = (long long *)ctx->d_st_rev;
     unsigned long long *sc = ctx->d_st_scalars;
     s.item_off = ctx->d_item_off; s.n_items = (int32_t *)(sc + 0 * 32);
@@ -789,8 +790,8 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     s.bin_count = ctx->d_st_bincnt; s.dp_bin = ctx->d_st_dpbin; s.dp_rank = ctx->d_st_dprank;
     s.bin_start = ctx->d_st_binstart; s.sorted = ctx->d_st_sorted; s.class_wave = ctx->d_st_classwave;
     s.cand = ctx->d_st_cand; s.n_cand = (unsigned *)(sc + 5 * 32); s.cand_flag = ctx->d_st_flag;
-    s.n_wv = (unsigned *)(sc + 6 * 32); s.n_cont = (unsigned *)(sc + 7 * 32); s.n_rev = (unsigned *)(sc + 8 * 32);
-    s.work = (unsigned *)(sc + 16 * 32);
+    s.n_wv = (unsigned *)(sc + 16 * 32); s.n_cont = (unsigned *)(sc + 24 * 32); s.n_rev = (unsigned *)(sc + 32 * 32);   // ST_NCLS counters each, 256 bytes apart
+    s.work = (unsigned *)(sc + 64 * 32);
     K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
     // few reads: the range finder as one wavefront per (read, pass) over per-READ scratch (launch_k1_parts), as in the
     // range-parallel mode; the unit kernels then take their per-wavefront scratch behind it
@@ -937,10 +938,10 @@ extern "C" mtr_status mtr_wait(mtr_ctx *ctx)
     HIPCHK(copy_sync(ctx, ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
     mtr_status st = check_status(ctx);
     if (ctx->last_staged && dbg()) {
-        unsigned long long sc[8 * 32]; int32_t cw[8];
+        unsigned long long sc[40 * 32]; int32_t cw[8];
         if (copy_sync(ctx, sc, ctx->d_st_scalars, sizeof sc, hipMemcpyDeviceToHost) == hipSuccess && copy_sync(ctx, cw, ctx->d_st_classwave, sizeof cw, hipMemcpyDeviceToHost) == hipSuccess)
             DBG("staged: items %d, ranges with a block %u (+ %u per-k work items), DP items %u (%u one wavefront each), candidate arena %.1f MB, cells %.2f GB, records parked %u; wavefronts per unit-length class %d %d %d %d",
-                (int)(int32_t)sc[0], (unsigned)sc[2 * 32], (unsigned)sc[7 * 32], (unsigned)sc[3 * 32], (unsigned)sc[6 * 32], (double)sc[1 * 32] / 1e6, (double)sc[4 * 32] / 1e9, (unsigned)sc[5 * 32], cw[1] - cw[0], cw[2] - cw[1], cw[3] - cw[2], cw[4] - cw[3]);
+                (int)(int32_t)sc[0], (unsigned)sc[2 * 32], st_sum(sc + 24 * 32), (unsigned)sc[3 * 32], st_sum(sc + 16 * 32), (double)sc[1 * 32] / 1e6, (double)sc[4 * 32] / 1e9, (unsigned)sc[5 * 32], cw[1] - cw[0], cw[2] - cw[1], cw[3] - cw[2], cw[4] - cw[3]);
     }
     if (st == MTR_ERR_OVERFLOW && ctx->last_staged) {
         // the batch outgrew a buffer of the staged mode: the per-read kernel takes it (same results)

@@ -112,7 +112,8 @@ static inline __host__ __device__ size_t k1_hist_bytes(int Lmax)
 #define K2_SLOT_SCORE 512          // int32 per slot
 #define K2_MEMO_N 32               // wrap_around_DP results remembered per candidate range (<= 11 k x 2 directions are made)
 #define K2_MEMO_UNIT 512           // bytes per remembered unit (MAX_PERIOD - 1 = 499 bases at most)
-#define K2_STEP_CACHE 128          // look-ahead decisions remembered per k-mer table and walk direction
+#define K2_STEP_CACHE 2048         // look-ahead decisions remembered per k-mer table and walk direction (direct-mapped), for a table in global memory;
+#define K2_STEP_CACHE_LDS 128      // for a table in LDS (windows up to K2_TAB_MAX_WIDTH; cleared per table, so kept small)
 #define K2_RMEMO_N 16              // revision rounds remembered per candidate range (the k of a range often polish to the same unit)
 struct K2Layout {
     size_t codes;                  // uint8 [cells]  traceback codes

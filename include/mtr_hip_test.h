@@ -30,7 +30,7 @@ mtr_status mtr_test_wrap_dp(mtr_ctx *ctx, int32_t n_tasks, const int32_t *read_i
 int32_t mtr_test_last_mode(const mtr_ctx *ctx);
 
 /* Event trace of the last run (debug aid for parity work): enable before mtr_run_resident.
- * Each event is 16 int32: [0]=type (2 search, 3 DP, 4 polish, 5 revise, 6 record), [1]=read index,
+ * Each event is 16 int32: [0]=type (2 search, 3 DP, 4 polish, 5 revise, 6 record, 7 per-read cost, 8 per-walk cost), [1]=read index,
  * then type-specific fields (the trace_ev() calls in mtr_amd/csrc/k2_units.hip.inc). */
 mtr_status mtr_set_trace(mtr_ctx *ctx, int32_t max_events);
 mtr_status mtr_get_trace(mtr_ctx *ctx, int32_t **out_events, int64_t *out_n);

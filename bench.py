@@ -174,7 +174,10 @@ def main():
     local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     xdev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    # MTR_BENCH_FORCE_DIST=1 (under torch.distributed.run with ONE rank): the N > 1 code path - process group, size exchange,
+    # gather to rank 0 - on a single GPU, to exercise the RCCL calls where only one GPU is available
+    dist_on = world > 1 or os.environ.get("MTR_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -196,7 +199,7 @@ def main():
     # between them, so the kernels of step s+1 are enqueued while step s is fetched (and while its last wavefronts finish:
     # a read is one wavefront's serial chain).  Every step does all of its work.  With an exchange step (N > 1) one more
     # context, so that the next kernel is already enqueued while the host waits for the gather of the previous step.
-    NCTX = int(os.environ.get("MTR_BENCH_CONTEXTS", "2" if world == 1 else "3"))
+    NCTX = int(os.environ.get("MTR_BENCH_CONTEXTS", "3" if dist_on else "2"))
     engs = [mtr_amd.Engine(device=local_rank) for _ in range(NCTX)]
     for e in engs:
         e.upload(reads)                                 # inputs resident in HBM before the timed region
@@ -229,14 +232,14 @@ def main():
     def finish(s, fetch=True, keep=False):
         e = engs[s % NCTX]
         e.wait()
-        if world > 1:
+        if dist_on:
             exchange(s, keep)
         elif fetch:
             e.fetch_packed_nocopy()                     # wire form -> pinned host memory of the context
         return e.kernel_times_ms()
 
     def sync():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -257,7 +260,7 @@ def main():
         dt = time.perf_counter() - t0
         for e in engs:
             e.set_overlapped(False)
-        if world > 1:
+        if dist_on:
             t = torch.tensor([dt], dtype=torch.float64, device=xdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -388,7 +391,7 @@ def main():
         print(json.dumps(out))
     for e in engs:
         e.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

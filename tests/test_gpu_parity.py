@@ -290,6 +290,26 @@ def test_kernel_modes_match_the_oracle(monkeypatch, oracle, mode):
     e.close()
 
 
+@pytest.mark.parametrize("mode", ["per_read", "staged"])
+def test_unit_lengths_around_the_two_column_pass(monkeypatch, oracle, mode):
+    """dp_forward2p_2c takes the two-parameter alignments of units of 65..128 bases (two columns per lane, even row stride);
+    64 and 129 are its neighbours' (one chunk / four chunks).  Units at and next to every boundary, odd and even, with few and
+    with many copies (rows), flanked and flush with the read's ends."""
+    for k, v in MODES[mode].items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.RandomState(20260)
+    reads = []
+    for u in (63, 64, 65, 66, 67, 99, 100, 101, 126, 127, 128, 129, 130, 255, 256):
+        for copies, pre, post in ((6, 40, 40), (12, 0, 300), (25, 500, 0)):
+            reads.append(synth.make_read(rng, u, copies, pre, post)[0])
+    e = mtr_amd.Engine()
+    got = e.process(reads)
+    for i, codes in enumerate(reads):
+        want = oracle.process(codes)
+        assert [tuple(r) for r in got[i]] == want, _diff_msg(i, want, [tuple(r) for r in got[i]])
+    e.close()
+
+
 def test_mode_policy_lone_and_overlapping_launches(monkeypatch):
     """include/mtr_hip.h, mtr_set_overlapped_launches: a batch of more than a few thousand reads runs as the staged chain while
     its launch has the GPU to itself, and in the per-read kernel when launches overlap - because another context's launch is

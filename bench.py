@@ -38,6 +38,12 @@ import hashlib
 import json
 import os
 import subprocess
+
+# The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4).  An RCCL communicator brings
+# streams of its own; with the default, the two context streams of a rank then share ONE hardware queue and their launches no
+# longer overlap (measured with one rank under RCCL: 80 ms a step instead of 52; with 8 queues 52 again).  Must be set before the
+# runtime initialises, i.e. before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import sys
 import tempfile
 import time
@@ -207,32 +213,74 @@ def main():
     wire_buf = [None] * NCTX
     gathered = {}
 
+    out_bufs = [None] * NCTX                            # rank 0: where the ranks' tables land, per context slot
+    works = [None] * NCTX                               # the gather still in flight on a context slot's buffers
+    agreed = {"cap": None}                              # bytes every rank sends per step, agreed once (the first exchange)
+
     def exchange(s, keep=False):
-        """the path's one exchange: wire-form tables device-to-device to rank 0"""
-        e = engs[s % NCTX]
-        wb = wire_buf[s % NCTX]
-        need = max(1 << 20, 700 * max(1, e.counters()["records"]))
+        """the path's one exchange: wire-form tables device-to-device to rank 0 (RCCL gather).
+        The first exchange (a warm-up step) all-gathers the table sizes and fixes the per-rank capacity; after that a step
+        ENQUEUES one gather of fixed-size buffers and goes on: a collective's kernel only gets onto the chip when wavefront slots
+        free up - the per-read kernel holds all of them until a launch drains - so a host that waits for it (or for a size
+        exchange in front of it) every step stalls the pipeline (measured with one rank: 63 instead of 52 ms a step)."""
+        i = s % NCTX
+        e = engs[i]
+        tdbg = [time.perf_counter()]
+        if works[i] is not None:                        # the previous gather out of this slot's buffer
+            works[i].wait(); works[i] = None
+        tdbg.append(time.perf_counter())
+        wb = wire_buf[i]
+        need = agreed["cap"] or max(1 << 20, 700 * max(1, e.counters()["records"]))
         if wb is None or wb.numel() < need:
-            wb = wire_buf[s % NCTX] = torch.empty(need * 5 // 4, dtype=torch.uint8, device="cuda")
+            wb = wire_buf[i] = torch.zeros(need * 5 // 4 if agreed["cap"] is None else need, dtype=torch.uint8, device="cuda")
+        tdbg.append(time.perf_counter())
         counts, total, nbytes = e.export_packed_device(wb.data_ptr(), wb.numel())
-        sizes = torch.tensor([nbytes, total, len(counts)], dtype=torch.int64, device=xdev)
-        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-        dist.all_gather(all_sizes, sizes)
-        width = max(int(x[0]) for x in all_sizes)
-        if wb.numel() < width:                          # another rank's table is larger than this rank's buffer: pad from a bigger one
-            nb = torch.zeros(width * 5 // 4, dtype=torch.uint8, device="cuda"); nb[: wb.numel()] = wb; wb = wire_buf[s % NCTX] = nb
-        pad = wb[: max(width, 1)].to(xdev)
-        out = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
-        dist.gather(pad, out, dst=0)
+        tdbg.append(time.perf_counter())
+        first = agreed["cap"] is None
+        all_sizes = None
+        if first or keep or backend != "nccl":
+            sizes = torch.tensor([nbytes, total, len(counts)], dtype=torch.int64, device=xdev)
+            all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+            dist.all_gather(all_sizes, sizes)
+        if first:
+            agreed["cap"] = max(1 << 20, max(int(x[0]) for x in all_sizes) * 3 // 2)
+            if wb.numel() < agreed["cap"]:
+                nb = torch.zeros(agreed["cap"], dtype=torch.uint8, device="cuda"); nb[: wb.numel()] = wb; wb = wire_buf[i] = nb
+        cap = agreed["cap"]
+        if nbytes > cap:
+            raise RuntimeError(f"record table of {nbytes} bytes exceeds the capacity agreed at the first exchange ({cap})")
+        pad = wb[:cap].to(xdev)
+        if rank == 0 and (out_bufs[i] is None or out_bufs[i][0].numel() != cap):
+            out_bufs[i] = [torch.empty(cap, dtype=torch.uint8, device=xdev) for _ in range(world)]
+        out = out_bufs[i] if rank == 0 else None
+        if os.environ.get("MTR_BENCH_XMODE") == "export" and not keep:
+            pass
+        elif backend == "nccl" and not keep:
+            works[i] = dist.gather(pad, out, dst=0, async_op=True)
+        else:
+            dist.gather(pad, out, dst=0)
+        tdbg.append(time.perf_counter())
+        if os.environ.get("MTR_BENCH_DEBUG") and rank == 0:
+            print("exchange step", s, "ms: wait prev gather %.2f, buffers %.2f, export %.2f, sizes+gather enqueue %.2f" %
+                  tuple((tdbg[j + 1] - tdbg[j]) * 1e3 for j in range(4)), file=sys.stderr)
         if rank == 0 and keep:
             gathered["blobs"] = [out[r][: int(all_sizes[r][0])].cpu().numpy().tobytes() for r in range(world)]
             gathered["records"] = [int(x[1]) for x in all_sizes]
             gathered["reads"] = [int(x[2]) for x in all_sizes]
 
+    def drain():
+        for i in range(NCTX):
+            if works[i] is not None:
+                works[i].wait(); works[i] = None
+
     def finish(s, fetch=True, keep=False):
         e = engs[s % NCTX]
+        t_w = time.perf_counter()
         e.wait()
-        if dist_on:
+        if os.environ.get("MTR_BENCH_DEBUG") and rank == 0:
+            print("step", s, "waited %.2f ms for the kernels" % ((time.perf_counter() - t_w) * 1e3), file=sys.stderr)
+        xmode = os.environ.get("MTR_BENCH_XMODE", "full")          # development: which part of the exchange step runs
+        if dist_on and xmode != "fetch":
             exchange(s, keep)
         elif fetch:
             e.fetch_packed_nocopy()                     # wire form -> pinned host memory of the context
@@ -256,6 +304,8 @@ def main():
             if s + depth < steps:
                 engs[(s + depth) % NCTX].run_async()
             k2.append(finish(s, fetch, keep=(s == steps - 1))["k2_units"])
+        if dist_on:
+            drain()                                     # every gather of the timed steps has completed inside the timed region
         sync()
         dt = time.perf_counter() - t0
         for e in engs:
@@ -272,6 +322,8 @@ def main():
         engs[w % NCTX].run_async()
         sync_k2.append(finish(w)["k2_units"])
         lone_mode = engs[w % NCTX].last_mode()
+    if dist_on:
+        drain()
     dt, k2_ms = timed(a.steps, fetch=True)
     dt_kernel = None
     if world == 1:

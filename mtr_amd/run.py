@@ -104,6 +104,7 @@ def spawn(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("GPU_MAX_HW_QUEUES", "8")        # RCCL's streams + the two context streams: more than the runtime's default of 4 hardware queues (bench.py)
         procs.append(subprocess.Popen([sys.executable, "-m", "mtr_amd.run", *argv], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     codes = [p.wait() for p in procs]
@@ -128,6 +129,7 @@ def gather_bytes(dist, torch, payload: bytes, rank, world, dev):
 
 
 def worker(a):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the HIP runtime starts (ranks started by torchrun rather than by main())
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))

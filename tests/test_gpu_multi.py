@@ -23,6 +23,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def eng():
+    # PyTorch brings its own HIP runtime (same soname as /opt/rocm's, which libmtr_hip.so is linked against): whichever is loaded
+    # first serves both, and torch does not find the GPU through the other one.  So, as bench.py and the launcher do: torch first.
+    import torch
+    torch.cuda.init()
     e = mtr_amd.Engine()
     yield e
     e.close()

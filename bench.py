@@ -226,8 +226,9 @@ def main():
         i = s % NCTX
         e = engs[i]
         tdbg = [time.perf_counter()]
-        if works[i] is not None:                        # the previous gather out of this slot's buffer
-            works[i].wait(); works[i] = None
+        if works[i] is not None:                        # the previous gather out of this slot's buffer (NCTX steps ago): it must
+            works[i].wait(); works[i] = None            # have READ the buffer before the engine's own stream writes it again
+            torch.cuda.current_stream().synchronize()
         tdbg.append(time.perf_counter())
         wb = wire_buf[i]
         need = agreed["cap"] or max(1 << 20, 700 * max(1, e.counters()["records"]))
@@ -272,6 +273,7 @@ def main():
         for i in range(NCTX):
             if works[i] is not None:
                 works[i].wait(); works[i] = None
+        torch.cuda.current_stream().synchronize()
 
     def finish(s, fetch=True, keep=False):
         e = engs[s % NCTX]

@@ -719,12 +719,12 @@ static bool use_staged(const mtr_ctx *ctx)
     const char *e = getenv("MTR_STAGED");
     if (e) return atoi(e) != 0;
     if (getenv("MTR_SPLIT")) return false;                 // an explicit choice between the two older modes
-    // [measured, host call on one resident batch of 2 kb reads: staged / range-parallel / per-read kernel] 1 read: 3.1-3.4 / 9 / 19 ms;
-    // 64: 5.2 / 16 / 30 ms; 2 000: 26 / 35 / 40 ms; 2 000 config-4 reads: 26 / 53 / 53 ms; 3 000: 35 / 33 / 40; 4 000: 47 / 40 / 47;
-    // 6 000: 63 / 53 / 55 ms; 100 reads of 42 kb: 226 / 291 / 1 151 ms -> the staged mode up to MTR_STAGED_MAX_READS (3 000) reads,
-    // the range-parallel mode up to 4 096 (use_split), the per-read kernel above.
+    // [measured, two contexts keeping two launches in flight, reads/s at 1 000 / 2 000 / 3 000 / 4 000 / 6 000 / 10 000 reads of 2 kb per
+    // batch] staged 123 / 150 / 162 / 171 / 179 / 168 k, range-parallel 71 / 123 / 149 / 156 / 92 k, per-read kernel 52 / 94 / 130 / 155 /
+    // 185 / 193 k (tests/dev/thresholds.sh): the chain up to MTR_STAGED_MAX_READS (5 000) reads whatever the caller does, above that
+    // only for a launch that has the GPU to itself (below).
     const char *m = getenv("MTR_STAGED_MAX_READS");
-    const long max_reads = m ? atol(m) : 3000;
+    const long max_reads = m ? atol(m) : 5000;
     if (ctx->n_reads <= max_reads) return true;
     // Larger batches [measured after the work queues got sub-queues, 10 000 reads of 2 kb]: a launch that has the chip to itself
     // takes 68-69 ms staged and 77-78 ms in the per-read kernel (no tail of slow reads); two contexts that keep two launches in

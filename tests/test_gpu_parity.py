@@ -316,7 +316,7 @@ def test_mode_policy_lone_and_overlapping_launches(monkeypatch):
     waiting to be collected, or because the caller has said so.  The records are the same in every case."""
     for k in ("MTR_STAGED", "MTR_SPLIT", "MTR_STAGED_MAX_READS", "MTR_STAGED_MAX_READS_LONE", "MTR_LPT"):
         monkeypatch.delenv(k, raising=False)
-    reads = [c for _, c in synth.make_reads("headline2k", 3600, 17)]
+    reads = [c for _, c in synth.make_reads("headline2k", 5600, 17)]
     a, b = mtr_amd.Engine(), mtr_amd.Engine()
     a.upload(reads); b.upload(reads)
     a.run()
@@ -324,7 +324,7 @@ def test_mode_policy_lone_and_overlapping_launches(monkeypatch):
     lone = [[tuple(r) for r in g] for g in a.fetch()]
     a.run_async(); b.run_async()                                   # b is launched while a's launch is pending
     a.wait(); b.wait()
-    assert a.last_mode() == "staged chain" and b.last_mode() != "staged chain"        # (range-parallel up to 4 096 reads, per-read kernel above)
+    assert a.last_mode() == "staged chain" and b.last_mode() != "staged chain"        # (the per-read kernel above MTR_STAGED_MAX_READS = 5 000 reads)
     assert [[tuple(r) for r in g] for g in b.fetch()] == lone
     a.set_overlapped(True)
     a.run()

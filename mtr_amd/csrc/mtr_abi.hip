@@ -820,6 +820,12 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         hipLaunchKernelGGL(mtr_k1_ranges, dim3((unsigned)waves1), dim3(64), 0, ctx->stream, a1);
         HIPCHK(hipGetLastError());
     }
+    // Few reads: not many more wavefronts than there can be work items.  Every wavefront of a persistent grid pulls from its
+    // queue at least once, and pulls on one counter complete one after the other (11 ns each): 4 096 - 8 192 wavefronts starting
+    // on a single read's dozens of items were 46 - 93 us per kernel, ~0.4 ms of a 3.2 ms call.  The bounds are generous
+    // estimates from the bases of the batch (2 kb reads have ~0.11 ranges, 0.02 alignments, 0.002 (range, k) searches and
+    // revisions per base; 42 kb reads fewer); a batch that has more items than wavefronts only takes longer.
+    auto capped = [&](int g, int64_t per_bases) { return (int)std::min<int64_t>(g, std::max<int64_t>(64, sumL / per_bases + 64)); };
     hipLaunchKernelGGL(mtr_k_items, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)ctx->d_rcount, s);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(mtr_k_item_table, dim3((unsigned)std::min(n, 4096)), dim3(256), 0, ctx->stream, a, s);
@@ -832,11 +838,11 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         int ww = pick_waves(ctx, std::max(n * 8, ctx->n_cu * 16), waves_per_cu(), pw, &tw);
         if (tw > ctx->scratch_bytes) ww = std::min(ww, waves);
         aw.scratch_per_wave = pw;
-        hipLaunchKernelGGL(mtr_k_walks, dim3((unsigned)ww), dim3(64), 0, ctx->stream, aw, s);
+        hipLaunchKernelGGL(mtr_k_walks, dim3((unsigned)capped(ww, 8)), dim3(64), 0, ctx->stream, aw, s);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(mtr_k_walks_k, dim3((unsigned)ww), dim3(64), 0, ctx->stream, aw, s);
+        hipLaunchKernelGGL(mtr_k_walks_k, dim3((unsigned)capped(ww, 32)), dim3(64), 0, ctx->stream, aw, s);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(mtr_k_gather, dim3((unsigned)ctx->n_cu * 16u), dim3(64), 0, ctx->stream, a, s);
+        hipLaunchKernelGGL(mtr_k_gather, dim3((unsigned)capped(ctx->n_cu * 16, 64)), dim3(64), 0, ctx->stream, a, s);
         HIPCHK(hipGetLastError());
     }
     if (s.lane_umax > 0) {
@@ -851,13 +857,13 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         if (s.lane_umax > 64) hipLaunchKernelGGL(mtr_k_dp2_lanes<128>, dim3(gdp), dim3(64), 0, ctx->stream, a, s, 3);
         HIPCHK(hipGetLastError());
     }
-    hipLaunchKernelGGL(mtr_k_dp2_waves, dim3((unsigned)waves_dp), dim3(64), 0, ctx->stream, a, s);
+    hipLaunchKernelGGL(mtr_k_dp2_waves, dim3((unsigned)capped(waves_dp, 16)), dim3(64), 0, ctx->stream, a, s);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(mtr_k_select, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a, s);
+    hipLaunchKernelGGL(mtr_k_select, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(mtr_k_revise, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a, s);
+    hipLaunchKernelGGL(mtr_k_revise, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(mtr_k_finish, dim3((unsigned)ctx->n_cu * 16u), dim3(64), 0, ctx->stream, a, s);
+    hipLaunchKernelGGL(mtr_k_finish, dim3((unsigned)capped(ctx->n_cu * 16, 64)), dim3(64), 0, ctx->stream, a, s);
     HIPCHK(hipGetLastError());
     SplitArgs sp{};
     sp.item_read = nullptr; sp.item_idx = nullptr; sp.item_off = ctx->d_item_off; sp.n_items = 0;

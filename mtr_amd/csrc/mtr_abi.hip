@@ -65,6 +65,7 @@ struct mtr_ctx {
     // resident batch
     int n_reads = 0, Lmax = 0;
     std::vector<int32_t> lens; std::vector<int64_t> roff;
+    long long packed_words = 0;
     uint32_t *d_packed = nullptr; int64_t *d_woff = nullptr; int32_t *d_lens = nullptr, *d_order = nullptr;
     int64_t *d_roff = nullptr; int32_t *d_rcount = nullptr, *d_rstart = nullptr, *d_rend = nullptr, *d_rw = nullptr; uint64_t *d_rdi = nullptr;
     int64_t total_rcap = 0;
@@ -78,7 +79,7 @@ struct mtr_ctx {
     int32_t *d_item_read = nullptr, *d_item_idx = nullptr, *d_cand_flag = nullptr; int64_t *d_item_off = nullptr; DevRecord *d_cand = nullptr;
     int64_t item_cap = 0; bool last_split = false, last_staged = false;
     // staged mode (k3_staged.hip.inc): fixed-capacity buffers of one batch
-    uint8_t *d_st_arena = nullptr, *d_st_codes = nullptr; int64_t *d_st_kc = nullptr; StDpItem *d_st_dp = nullptr;
+    uint8_t *d_st_arena = nullptr; int64_t *d_st_kc = nullptr; StDpItem *d_st_dp = nullptr;
     unsigned *d_st_bincnt = nullptr; int32_t *d_st_dpbin = nullptr, *d_st_dprank = nullptr, *d_st_binstart = nullptr, *d_st_sorted = nullptr, *d_st_classwave = nullptr;
     DevRecord *d_st_cand = nullptr; int32_t *d_st_flag = nullptr; unsigned long long *d_st_scalars = nullptr;
     int32_t *d_st_wv = nullptr, *d_st_res = nullptr; int4 *d_st_items = nullptr, *d_st_cont = nullptr; int64_t *d_st_rev = nullptr;
@@ -254,7 +255,7 @@ static void release_batch_buffers(mtr_ctx *ctx)
     dfree(ctx->d_ovf_records); dfree(ctx->d_rec_base); dfree(ctx->d_ovf_order); dfree(ctx->d_src);
     dfree(ctx->d_item_read); dfree(ctx->d_item_idx); dfree(ctx->d_cand_flag); dfree(ctx->d_item_off); dfree(ctx->d_cand); ctx->item_cap = 0;
     dfree(ctx->d_tail); dfree(ctx->d_tail_off);
-    dfree(ctx->d_st_arena); dfree(ctx->d_st_codes); dfree(ctx->d_st_kc); dfree(ctx->d_st_dp); dfree(ctx->d_st_bincnt); dfree(ctx->d_st_dpbin); dfree(ctx->d_st_dprank);
+    dfree(ctx->d_st_arena); dfree(ctx->d_st_kc); dfree(ctx->d_st_dp); dfree(ctx->d_st_bincnt); dfree(ctx->d_st_dpbin); dfree(ctx->d_st_dprank);
     dfree(ctx->d_st_binstart); dfree(ctx->d_st_sorted); dfree(ctx->d_st_classwave); dfree(ctx->d_st_cand); dfree(ctx->d_st_flag); dfree(ctx->d_st_scalars); dfree(ctx->d_st_wv); dfree(ctx->d_st_res); dfree(ctx->d_st_items); dfree(ctx->d_st_cont); dfree(ctx->d_st_rev);
     dfree(ctx->d_lpt_count); dfree(ctx->d_lpt_start); dfree(ctx->d_lpt_bin); dfree(ctx->d_lpt_rank); dfree(ctx->d_lpt_order);
     dfree(ctx->d_wire_bytes); dfree(ctx->d_wire_off); dfree(ctx->d_wire);
@@ -449,6 +450,7 @@ static mtr_status upload_batch(mtr_ctx *ctx, mtr_file_state *fs, const uint32_t 
     HIPCHK(ensure_dev(ctx, ctx->d_item_off, ((size_t)n + 1) * 8));
     HIPCHK(hipMemcpyAsync(ctx->d_packed, packed, (size_t)words * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_packed + words, 0, 80 * 4, ctx->stream));
+    ctx->packed_words = (long long)words + 80;
     HIPCHK(hipMemcpyAsync(ctx->d_woff, woff, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_lens, lens, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -568,6 +570,7 @@ static void k2_args(mtr_ctx *ctx, K2Args &a, size_t per_wave)
     a.trace = ctx->d_trace; a.trace_cap = ctx->trace_cap; a.trace_n = ctx->d_trace_n;
     a.trace_mask = getenv("MTR_TRACE_MASK") ? (int32_t)strtol(getenv("MTR_TRACE_MASK"), nullptr, 0) : -1;
     a.dp16_max_rows = dp16_max_rows();
+    a.packed_words = ctx->packed_words;
 }
 
 // One wavefront per read as TWO kernels: the range kernel, then the unit kernel (mtr_k_units) with its work queue ordered by
@@ -702,11 +705,14 @@ static mtr_status launch_split(mtr_ctx *ctx)
 // of the batch one per lane, then tracebacks + selection + revision per range, then the replay of the sequential loop.
 // One stream, no host round trip; every buffer has a capacity fixed here, and a batch that outgrows one is run again
 // by the per-read kernel (mtr_wait).  MTR_STAGED=0/1 forces it off/on.
-static int staged_lane_umax()
-{   // units up to this length are aligned one DP per lane (mtr_k_dp2_lanes), longer ones one wavefront per DP (MTR_STAGED_LANE_UMAX)
-    const char *e = getenv("MTR_STAGED_LANE_UMAX");
-    const int v = e ? atoi(e) : 0;
-    return v < 0 ? 0 : (v > ST_UMAX ? ST_UMAX : v);
+static int staged_quad_min(int64_t bases)
+{   // Alignments of units of up to 128 bases go four per wavefront (mtr_k_dp2_quads) in batches of at least 2 M bases (1 000 reads
+    // of 2 kb): smaller ones do not give every SIMD a wavefront that way, and then more wavefronts count for more than fewer
+    // instructions per row.  The value is the number of such alignments the batch must have (checked on the device).
+    // MTR_QUAD_MIN forces it (tests: 1 = always, 0 = never).
+    const char *e = getenv("MTR_QUAD_MIN");
+    if (e) { const long v = atol(e); return (int)(v < 0 ? 0 : (v > 0x7fffffff ? 0x7fffffff : v)); }
+    return bases >= 2000000 ? 1024 : 0;
 }
 static int pending_launches(int device)
 {
@@ -751,34 +757,40 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     s.arena_cap = std::min<int64_t>(sumL * 1024 + (1 << 20), (int64_t)((double)free_b * 0.2) + (ctx->d_st_arena ? sumL * 1024 : 0));
     s.kc_cap = (int32_t)std::min<int64_t>(ctx->total_rcap, sumL / 8 + 4096);
     s.dp_cap = (int32_t)std::min<int64_t>(0x7fffff00, sumL / 8 + 4096);
-    s.sorted_cap = s.dp_cap + 64 * 512;
+    s.sorted_cap = s.dp_cap + 4 * ST_QCLASSES;
     s.cand_cap = (int32_t)std::min<int64_t>(0x7fffff00, (int64_t)n * 8 + sumL / 256 + 1024);
-    {
-        int64_t want = std::max<int64_t>(sumL * 1024, (int64_t)256 << 20);
-        const char *e = getenv("MTR_STAGED_CODES_GB");
-        if (e) want = (int64_t)(atof(e) * (double)(1ll << 30));
-        s.codes_cap = std::min<int64_t>(want, (int64_t)((double)free_b * 0.5) + (ctx->d_st_codes ? want : 0));
-        if (staged_lane_umax() == 0) s.codes_cap = 4096;        // the cell arena belongs to the lane kernels alone
+    long test_rev_cap = -1, test_cont_cap = -1;
+    if (const char *e = getenv("MTR_TEST_STAGED_CAPS")) {
+        // tests only: "arena=<bytes>,kc=<n>,dp=<n>,cand=<n>,cont=<n>,rev=<n>" shrinks capacities so that every overflow path of the
+        // chain is taken (the batch must then come out of the per-read kernel with the same records)
+        auto cap = [&](const char *key) -> long { const char *q = strstr(e, key); return q ? atol(q + strlen(key)) : -1; };
+        if (cap("arena=") >= 0) s.arena_cap = cap("arena=");
+        if (cap("kc=") >= 0) s.kc_cap = (int32_t)cap("kc=");
+        if (cap("dp=") >= 0) s.dp_cap = (int32_t)cap("dp=");
+        if (cap("cand=") >= 0) s.cand_cap = (int32_t)cap("cand=");
+        test_cont_cap = cap("cont="); test_rev_cap = cap("rev=");
+        s.sorted_cap = s.dp_cap + 4 * ST_QCLASSES;
     }
-    HIPCHK(ensure_dev(ctx, ctx->d_st_arena, (size_t)s.arena_cap)); HIPCHK(ensure_dev(ctx, ctx->d_st_codes, (size_t)s.codes_cap));
+    HIPCHK(ensure_dev(ctx, ctx->d_st_arena, (size_t)s.arena_cap));
     HIPCHK(ensure_dev(ctx, ctx->d_st_kc, (size_t)s.kc_cap * 8)); HIPCHK(ensure_dev(ctx, ctx->d_st_dp, (size_t)s.dp_cap * sizeof(StDpItem)));
     HIPCHK(ensure_dev(ctx, ctx->d_st_bincnt, (size_t)ST_NBINS * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_binstart, ((size_t)ST_NBINS + 1) * 4));
     HIPCHK(ensure_dev(ctx, ctx->d_st_dpbin, (size_t)s.dp_cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_dprank, (size_t)s.dp_cap * 4));
-    HIPCHK(ensure_dev(ctx, ctx->d_st_sorted, (size_t)s.sorted_cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_classwave, 8 * 4));
+    HIPCHK(ensure_dev(ctx, ctx->d_st_sorted, (size_t)s.sorted_cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_classwave, 16 * 4));
     HIPCHK(ensure_dev(ctx, ctx->d_st_cand, (size_t)s.cand_cap * sizeof(DevRecord))); HIPCHK(ensure_dev(ctx, ctx->d_st_flag, (size_t)std::max<int64_t>(ctx->total_rcap, 1) * 4));
     // device scalars, each on a 256-byte line of its own (same-line atomics complete one after the other), then the work queues
     const size_t st_scalar_bytes = 64 * 256 + (size_t)ST_N_QUEUES * WQ_WORDS * 4;
     HIPCHK(ensure_dev(ctx, ctx->d_st_scalars, st_scalar_bytes));
     HIPCHK(ensure_dev(ctx, ctx->d_st_wv, (size_t)ST_NCLS * (size_t)s.dp_cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_res, (size_t)s.dp_cap * 16 * 4));
-    s.lane_umax = staged_lane_umax(); s.wv_items = ctx->d_st_wv; s.dp_res = ctx->d_st_res;
+    s.quad_min = staged_quad_min(sumL); s.wv_items = ctx->d_st_wv; s.dp_res = ctx->d_st_res;
     s.item_cap = (int32_t)std::min<int64_t>(0x7fffff00, ctx->total_rcap);
     HIPCHK(ensure_dev(ctx, ctx->d_st_items, (size_t)std::max(s.item_cap, 1) * sizeof(int4)));
     s.item_tab = ctx->d_st_items;
     s.cont_cap = (int32_t)std::min<int64_t>(0x7fffff00, 2 * (int64_t)s.kc_cap);
+    if (test_cont_cap >= 0) s.cont_cap = (int32_t)test_cont_cap;
     HIPCHK(ensure_dev(ctx, ctx->d_st_cont, (size_t)ST_NCLS * (size_t)s.cont_cap * sizeof(int4)));
     s.cont = ctx->d_st_cont;
     s.k_first = getenv("MTR_STAGED_K_FIRST") ? std::max(1, atoi(getenv("MTR_STAGED_K_FIRST"))) : 3;
-    s.rev_cap = s.kc_cap;
+    s.rev_cap = test_rev_cap >= 0 ? (int32_t)test_rev_cap : s.kc_cap;
     HIPCHK(ensure_dev(ctx, ctx->d_st_rev, (size_t)ST_NCLS * (size_t)s.rev_cap * 8));
     s.rev_items = (long long *)ctx->d_st_rev;
     unsigned long long *sc = ctx->d_st_scalars;
@@ -786,9 +798,8 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     s.arena = ctx->d_st_arena; s.arena_cur = sc + 1 * 32;
     s.kc_items = (long long *)ctx->d_st_kc; s.n_kc = (unsigned *)(sc + 2 * 32);
     s.dp = ctx->d_st_dp; s.n_dp = (unsigned *)(sc + 3 * 32);
-    s.codes = ctx->d_st_codes; s.codes_cur = sc + 4 * 32;
     s.bin_count = ctx->d_st_bincnt; s.dp_bin = ctx->d_st_dpbin; s.dp_rank = ctx->d_st_dprank;
-    s.bin_start = ctx->d_st_binstart; s.sorted = ctx->d_st_sorted; s.class_wave = ctx->d_st_classwave;
+    s.bin_start = ctx->d_st_binstart; s.sorted = ctx->d_st_sorted; s.quad_cls = ctx->d_st_classwave;
     s.cand = ctx->d_st_cand; s.n_cand = (unsigned *)(sc + 5 * 32); s.cand_flag = ctx->d_st_flag;
     s.n_wv = (unsigned *)(sc + 16 * 32); s.n_cont = (unsigned *)(sc + 24 * 32); s.n_rev = (unsigned *)(sc + 32 * 32);   // ST_NCLS counters each, 256 bytes apart
     s.work = (unsigned *)(sc + 64 * 32);
@@ -809,10 +820,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     K2Args a{}; k2_args(ctx, a, per_wave);
     HIPCHK(hipMemsetAsync(ctx->d_trace_n, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_st_scalars, 0, st_scalar_bytes, ctx->stream));
-    if (s.lane_umax > 0) {
-        HIPCHK(hipMemsetAsync(ctx->d_st_bincnt, 0, (size_t)ST_NBINS * 4, ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->d_st_sorted, 0xFF, (size_t)s.sorted_cap * 4, ctx->stream));
-    }
+    if (s.quad_min > 0) HIPCHK(hipMemsetAsync(ctx->d_st_bincnt, 0, (size_t)ST_NBINS * 4, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     if (parts) { mtr_status ps = launch_k1_parts(ctx); if (ps != MTR_OK) return ps; }
     else {
@@ -845,16 +853,12 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         hipLaunchKernelGGL(mtr_k_gather, dim3((unsigned)capped(ctx->n_cu * 16, 64)), dim3(64), 0, ctx->stream, a, s);
         HIPCHK(hipGetLastError());
     }
-    if (s.lane_umax > 0) {
-        hipLaunchKernelGGL(mtr_k_bins, dim3(1), dim3(512), 0, ctx->stream, s);
+    if (s.quad_min > 0) {
+        hipLaunchKernelGGL(mtr_k_qbins, dim3(1), dim3(1024), 0, ctx->stream, s);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(mtr_k_scatter, dim3(512), dim3(256), 0, ctx->stream, s);
+        hipLaunchKernelGGL(mtr_k_qscatter, dim3((unsigned)capped(512, 16384)), dim3(256), 0, ctx->stream, s);
         HIPCHK(hipGetLastError());
-        const unsigned gdp = (unsigned)ctx->n_cu * 16u;
-        hipLaunchKernelGGL(mtr_k_dp2_lanes<16>, dim3(gdp), dim3(64), 0, ctx->stream, a, s, 0);
-        if (s.lane_umax > 16) hipLaunchKernelGGL(mtr_k_dp2_lanes<32>, dim3(gdp), dim3(64), 0, ctx->stream, a, s, 1);
-        if (s.lane_umax > 32) hipLaunchKernelGGL(mtr_k_dp2_lanes<64>, dim3(gdp), dim3(64), 0, ctx->stream, a, s, 2);
-        if (s.lane_umax > 64) hipLaunchKernelGGL(mtr_k_dp2_lanes<128>, dim3(gdp), dim3(64), 0, ctx->stream, a, s, 3);
+        hipLaunchKernelGGL(mtr_k_dp2_quads, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
         HIPCHK(hipGetLastError());
     }
     hipLaunchKernelGGL(mtr_k_dp2_waves, dim3((unsigned)capped(waves_dp, 16)), dim3(64), 0, ctx->stream, a, s);
@@ -944,10 +948,10 @@ extern "C" mtr_status mtr_wait(mtr_ctx *ctx)
     HIPCHK(copy_sync(ctx, ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
     mtr_status st = check_status(ctx);
     if (ctx->last_staged && dbg()) {
-        unsigned long long sc[40 * 32]; int32_t cw[8];
+        unsigned long long sc[40 * 32]; int32_t cw[10];
         if (copy_sync(ctx, sc, ctx->d_st_scalars, sizeof sc, hipMemcpyDeviceToHost) == hipSuccess && copy_sync(ctx, cw, ctx->d_st_classwave, sizeof cw, hipMemcpyDeviceToHost) == hipSuccess)
-            DBG("staged: items %d, ranges with a block %u (+ %u per-k work items), DP items %u (%u one wavefront each), candidate arena %.1f MB, cells %.2f GB, records parked %u; wavefronts per unit-length class %d %d %d %d",
-                (int)(int32_t)sc[0], (unsigned)sc[2 * 32], st_sum(sc + 24 * 32), (unsigned)sc[3 * 32], st_sum(sc + 16 * 32), (double)sc[1 * 32] / 1e6, (double)sc[4 * 32] / 1e9, (unsigned)sc[5 * 32], cw[1] - cw[0], cw[2] - cw[1], cw[3] - cw[2], cw[4] - cw[3]);
+            DBG("staged: items %d, ranges with a block %u (+ %u per-k work items), DP items %u (%u work-list entries of one wavefront each), candidate arena %.1f MB, records parked %u; alignments four per wavefront: %d slots (8..1 columns per lane: %d %d %d %d %d %d %d %d)",
+                (int)(int32_t)sc[0], (unsigned)sc[2 * 32], st_sum(sc + 24 * 32), (unsigned)sc[3 * 32], st_sum(sc + 16 * 32), (double)sc[1 * 32] / 1e6, (unsigned)sc[5 * 32], cw[8], cw[1] - cw[0], cw[2] - cw[1], cw[3] - cw[2], cw[4] - cw[3], cw[5] - cw[4], cw[6] - cw[5], cw[7] - cw[6], cw[8] - cw[7]);
     }
     if (st == MTR_ERR_OVERFLOW && ctx->last_staged) {
         // the batch outgrew a buffer of the staged mode: the per-read kernel takes it (same results)

@@ -217,6 +217,7 @@ struct K2Args {
     int32_t *trace; int32_t trace_cap; unsigned int *trace_n; int32_t trace_mask;   // bit t = record events of type t
     int32_t dp16_max_rows;         // DPs of up to this many rows may use the 16-bit kernels (tests set 0 to force the 32-bit ones)
     long long cells_cap;           // > 0: the scratch layout's cell region is this small (k2_layout)
+    long long packed_words;        // words readable at b.packed (the batch's image + its zero slack): clamp of window prefetches
 };
 
 // -a alignments (pretty_print_alignment, wrap_around_DP.c:57-213) of a list of reported repeats of the resident batch

@@ -264,18 +264,22 @@ def test_read_of_the_maximum_length(eng, oracle):
 
 # ---- the kernel modes: same records as one wavefront per read -----------------------------------------------------------
 MODES = {"per_read": {"MTR_STAGED": "0", "MTR_SPLIT": "0"}, "range_parallel": {"MTR_STAGED": "0", "MTR_SPLIT": "1"},
-         "staged": {"MTR_STAGED": "1"}, "staged_lanes16": {"MTR_STAGED": "1", "MTR_STAGED_LANE_UMAX": "16"},
-         "staged_lanes128": {"MTR_STAGED": "1", "MTR_STAGED_LANE_UMAX": "128"},
-         "staged_overflow": {"MTR_STAGED": "1", "MTR_STAGED_LANE_UMAX": "128", "MTR_STAGED_CODES_GB": "0.001"}}
+         "staged": {"MTR_STAGED": "1", "MTR_QUAD_MIN": "0"}, "staged_quads": {"MTR_STAGED": "1", "MTR_QUAD_MIN": "1"},
+         "staged_overflow_arena": {"MTR_STAGED": "1", "MTR_TEST_STAGED_CAPS": "arena=200000"},
+         "staged_overflow_kc": {"MTR_STAGED": "1", "MTR_TEST_STAGED_CAPS": "kc=40"},
+         "staged_overflow_cont": {"MTR_STAGED": "1", "MTR_TEST_STAGED_CAPS": "cont=10"},
+         "staged_overflow_dp": {"MTR_STAGED": "1", "MTR_QUAD_MIN": "1", "MTR_TEST_STAGED_CAPS": "dp=50"},
+         "staged_overflow_rev": {"MTR_STAGED": "1", "MTR_TEST_STAGED_CAPS": "rev=3"},
+         "staged_overflow_cand": {"MTR_STAGED": "1", "MTR_TEST_STAGED_CAPS": "cand=5"}}
 
 
 @pytest.mark.parametrize("mode", sorted(MODES))
 def test_kernel_modes_match_the_oracle(monkeypatch, oracle, mode):
     """per_read: one wavefront per read (the reference's sequential range loop).  range_parallel: every candidate range its
     own work item + replay of the sequential pruning.  staged: ranges -> walks -> every two-parameter DP its own work item
-    (one wavefront each, or with MTR_STAGED_LANE_UMAX one DP per LANE for short units) -> selection/revision -> replay;
-    staged_overflow: a cell arena far too small, so the library must fall back to the per-read kernel.  All must give
-    the oracle's records (and so each other's)."""
+    (one wavefront each; staged_quads: units of 17..128 bases four per wavefront whatever the batch size) -> selection/revision
+    -> replay; staged_overflow_*: one of the chain's capacities far too small, so the library must fall back to the per-read kernel
+    (the kernels behind the overflow must not walk the half-written work lists).  All must give the oracle's records."""
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)
     e = mtr_amd.Engine()
@@ -284,13 +288,15 @@ def test_kernel_modes_match_the_oracle(monkeypatch, oracle, mode):
     reads += [rng.randint(0, 4, size=n).astype(np.uint8) for n in (1, 9, 31, 1000)]
     reads += [np.tile(np.array([3, 3, 0, 2, 2, 2], np.uint8), 700), c3_read := synth.make_reads("c3", 1, 5)[0][1]]
     got = e.process(reads)
+    if mode.startswith("staged"):
+        assert e.last_mode() == ("per-read kernel" if "overflow" in mode else "staged chain")
     for i, codes in enumerate(reads):
         want = oracle.process(codes)
         assert [tuple(r) for r in got[i]] == want, _diff_msg(i, want, [tuple(r) for r in got[i]])
     e.close()
 
 
-@pytest.mark.parametrize("mode", ["per_read", "staged"])
+@pytest.mark.parametrize("mode", ["per_read", "staged", "staged_quads"])
 def test_unit_lengths_around_the_two_column_pass(monkeypatch, oracle, mode):
     """dp_forward2p_2c takes the two-parameter alignments of units of 65..128 bases (two columns per lane, even row stride);
     64 and 129 are its neighbours' (one chunk / four chunks).  Units at and next to every boundary, odd and even, with few and
@@ -338,7 +344,7 @@ def test_mode_policy_lone_and_overlapping_launches(monkeypatch):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("mode", ["range_parallel", "staged", "staged_lanes128"])
+@pytest.mark.parametrize("mode", ["range_parallel", "staged", "staged_quads"])
 def test_kernel_modes_golden(monkeypatch, mode):
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)

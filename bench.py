@@ -20,14 +20,17 @@ wire-form tables go device-to-device to rank 0 over RCCL (mtr_export_packed_devi
 config 4 — one set of 100 000 mixed-unit reads, contiguous blocks balanced by sum of lengths; rank 0 checks the sha256 of
 the gathered stream against the known answer of the CPU oracle (tests/golden/c4_100k_wire.json) and reports ranks_seen.
 
-roofline: the dominant kernel is mtr_k_reads.  `achieved` = algorithmic HBM bytes of one launch (B_alg =
-ceil(L/4) + 576 R + sum over the REFERENCE's DPs of ceil(cells/2), every DP counted as spilled; the DPs the kernel answers
-from its memo are part of the reference's work and are counted) / the kernel's average duration measured with HIP events
-on the launch stream.  The path is NOT HBM-bound (row-serial integer recurrence: instruction issue + cross-lane latency):
-`valu` prices the reference's DP cell updates against the VALU peak, `issue` is the measured VALU issue utilisation.
-`traffic` (HBM bytes per launch, FETCH_SIZE x 2 + WRITE_SIZE as the gfx950 guide prescribes) and `issue` come from the
-rocprofv3 PMC passes committed under profiles/ (profiles/pmc_latest.json); they are reported only while the kernel
-sources are the ones that were profiled (sha of mtr_amd/csrc), else null.
+roofline: a launch is the staged chain (k3_staged.hip.inc: ranges -> unit search -> alignments -> selection -> revisions -> replay,
+one stream, no host round trip); its duration and the durations of its phases are measured with HIP events on the launch stream
+inside the timed region (mtr_get_kernel_times), the dominant phases are the wrap-around DP kernels mtr_k_dp2_quads (alignments) and
+mtr_k_revise_quads (revisions).  The path is bound by VALU instruction issue (row-serial integer max-plus recurrence),
+so `bound` is "valu-issue": `achieved` = the REFERENCE's DP cell updates of one launch x 7 integer operations / the
+launch's duration, `peak` = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz lane-operations per second; `frac_by_step` prices the same work
+against the driver-visible step time.  `hbm` keeps the HBM view of SURVEY.md 8d: algorithmic bytes B_alg = ceil(L/4) + 576 R + sum over
+the REFERENCE's DPs of ceil(cells/2) with EVERY DP counted as spilled (the DPs the kernels answer from their memo are the reference's
+work and are counted), `traffic` (HBM bytes per launch, FETCH_SIZE x 2 + WRITE_SIZE as the gfx950 guide prescribes) and `issue`
+(SQ_INSTS_VALU x 2 cycles / SIMD-cycles of the launch) from the rocprofv3 PMC passes committed under profiles/ (profiles/pmc_latest.json),
+reported only while the kernel sources are the ones that were profiled (sha of mtr_amd/csrc), else null.
 cpu_baseline: rank 0, N = 1 only — the reference mTR binary (oracle/_ref/mTR_ref, kind "reference") when it travelled
 with the repo, else the CPU oracle (kind "port"), on the first reads of the same workload, 1 core (and all cores).
 """
@@ -61,11 +64,11 @@ OPS_PER_CELL = 7                 # ~7 integer ops per DP cell up
 
 
 def kernel_sources_sha():
-    # the sources of the dominant kernel (mtr_k_reads) and the flags it is built with; the host side of the library
-    # (mtr_abi.hip) and the staged mode's kernels (k3_staged.hip.inc) are not part of it
+    # the sources of the kernels and the flags they are built with
     h = hashlib.sha256()
     d = os.path.join(ROOT, "mtr_amd", "csrc")
-    for f in ("device_util.hip.inc", "dp_wrap.hip.inc", "k1_ranges.hip.inc", "k2_units.hip.inc", "mtr_common.h", "min_missing_table.h"):
+    for f in ("device_util.hip.inc", "dp_wrap.hip.inc", "dp_quad.hip.inc", "k1_ranges.hip.inc", "k2_units.hip.inc", "k3_staged.hip.inc", "mtr_common.h",
+              "min_missing_table.h", "mtr_abi.hip"):
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     h.update(open(os.path.join(ROOT, "mtr_amd", "build.py"), "rb").read())
@@ -217,6 +220,18 @@ def main():
     works = [None] * NCTX                               # the gather still in flight on a context slot's buffers
     agreed = {"cap": None}                              # bytes every rank sends per step, agreed once (the first exchange)
 
+    host_bufs = [None] * NCTX                           # rank 0: the gathered tables in pinned host memory (where N = 1 ends too)
+
+    def to_host(i):
+        """rank 0: the tables a finished gather left on its GPU go to pinned host memory (one copy per rank's buffer, enqueued)"""
+        if rank != 0 or out_bufs[i] is None or backend != "nccl":
+            return                                      # (gloo: the gather's output already is host memory)
+        cap = out_bufs[i][0].numel()
+        if host_bufs[i] is None or host_bufs[i].numel() != cap * world:
+            host_bufs[i] = torch.empty(cap * world, dtype=torch.uint8, pin_memory=True)
+        for r in range(world):
+            host_bufs[i][r * cap:(r + 1) * cap].copy_(out_bufs[i][r], non_blocking=True)
+
     def exchange(s, keep=False):
         """the path's one exchange: wire-form tables device-to-device to rank 0 (RCCL gather).
         The first exchange (a warm-up step) all-gathers the table sizes and fixes the per-rank capacity; after that a step
@@ -228,6 +243,7 @@ def main():
         tdbg = [time.perf_counter()]
         if works[i] is not None:                        # the previous gather out of this slot's buffer (NCTX steps ago): it must
             works[i].wait(); works[i] = None            # have READ the buffer before the engine's own stream writes it again
+            to_host(i)
             torch.cuda.current_stream().synchronize()
         tdbg.append(time.perf_counter())
         wb = wire_buf[i]
@@ -260,6 +276,7 @@ def main():
             works[i] = dist.gather(pad, out, dst=0, async_op=True)
         else:
             dist.gather(pad, out, dst=0)
+            to_host(i)
         tdbg.append(time.perf_counter())
         if os.environ.get("MTR_BENCH_DEBUG") and rank == 0:
             print("exchange step", s, "ms: wait prev gather %.2f, buffers %.2f, export %.2f, sizes+gather enqueue %.2f" %
@@ -273,6 +290,7 @@ def main():
         for i in range(NCTX):
             if works[i] is not None:
                 works[i].wait(); works[i] = None
+                to_host(i)
         torch.cuda.current_stream().synchronize()
 
     def finish(s, fetch=True, keep=False):
@@ -295,8 +313,6 @@ def main():
 
     def timed(steps, fetch=True):
         k2 = []
-        for e in engs:                                  # the steps of the timed region overlap (two contexts): say so, as the
-            e.set_overlapped(NCTX > 1)                  # command-line driver does; the warm-up steps run one at a time
         sync()
         t0 = time.perf_counter()
         depth = NCTX - 1                                # steps enqueued ahead of the one being finished
@@ -305,24 +321,30 @@ def main():
         for s in range(steps):
             if s + depth < steps:
                 engs[(s + depth) % NCTX].run_async()
-            k2.append(finish(s, fetch, keep=(s == steps - 1))["k2_units"])
+            k2.append(finish(s, fetch, keep=(s == steps - 1)))
         if dist_on:
             drain()                                     # every gather of the timed steps has completed inside the timed region
         sync()
         dt = time.perf_counter() - t0
-        for e in engs:
-            e.set_overlapped(False)
         if dist_on:
             t = torch.tensor([dt], dtype=torch.float64, device=xdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, k2
 
+    # the REFERENCE's work on this batch (its DP calls and cells, what it answers from a repeated call included): one launch of the
+    # per-read kernel, which runs the reference's own sequential range loop (the chain also searches ranges that loop removes)
+    os.environ["MTR_STAGED"] = "0"
+    try:
+        engs[0].run()
+        ref_cnt = engs[0].counters()
+    finally:
+        del os.environ["MTR_STAGED"]
     sync_k2 = []
     lone_mode = None
     for w in range(a.warmup):                           # warm-up steps run one at a time (un-overlapped kernel times)
         engs[w % NCTX].run_async()
-        sync_k2.append(finish(w)["k2_units"])
+        sync_k2.append(finish(w))
         lone_mode = engs[w % NCTX].last_mode()
     if dist_on:
         drain()
@@ -337,11 +359,15 @@ def main():
         value = n_job * a.steps / dt
         # algorithmic bytes of one launch (this rank's batch): the reference's DP cells = computed + answered from the memo
         sumL4 = sum((len(r) + 3) // 4 for r in reads)
-        cells = cnt["dp_cells"] + cnt["revise_dp_cells"] + cnt["memo_cells"]
-        b_alg = sumL4 + 576 * cnt["records"] + (cells + 1) // 2
-        k2_avg_s = float(np.mean(k2_ms)) / 1e3
+        cells = ref_cnt["dp_cells"] + ref_cnt["revise_dp_cells"] + ref_cnt["memo_cells"]
+        b_alg = sumL4 + 576 * ref_cnt["records"] + (cells + 1) // 2
+        k2_avg_s = float(np.mean([k["k2_units"] for k in k2_ms])) / 1e3
         achieved_gbs = b_alg / k2_avg_s / 1e9
         valu_ops = cells * OPS_PER_CELL / k2_avg_s
+        step_s = dt / a.steps
+        phases = sorted({p for k in k2_ms for p in k if p.startswith("chain_")})
+        phase_ms = {p[6:]: float(np.mean([k.get(p, 0.0) for k in k2_ms])) for p in phases}
+        phase_ms_alone = {p[6:]: float(np.mean([k.get(p, 0.0) for k in sync_k2])) for p in phases} if sync_k2 else None
         traffic, issue, prof_tag = profiled_counters()
         wire_bytes = len(eng.fetch_packed()[0]) if world == 1 else None
         if a.strong:
@@ -366,24 +392,31 @@ def main():
             "config": {"workload": workload, "reads_per_gpu": n_local,
                        "parallelism": f"reads sharded over {world} GPU(s), wire-form record tables gathered to rank 0" if world > 1
                                       else "1 GPU, record tables fetched to pinned host memory in wire form"},
-            "value_definition": "steps end with the record tables in host memory (wire form, mtr_fetch_results_packed)" if world == 1
-                                else "steps end with the record tables of every rank gathered on rank 0's GPU (RCCL)",
+            "value_definition": "steps end with the record tables in host memory (wire form, mtr_fetch_results_packed)" if not dist_on
+                                else "steps end with the record tables of every rank in rank 0's pinned host memory (wire form: RCCL gather to rank 0's GPU, one copy to the host)",
             "ms_per_read": dt / a.steps * 1e3 / max(n_job, 1),
-            "kernels_ms": {"mtr_k_reads": float(np.mean(k2_ms)),
+            "kernels_ms": {"launch": k2_avg_s * 1e3, "phases": phase_ms,
                            "note": "HIP-event durations over the timed region; consecutive steps overlap on the GPU, so a launch shares the chip with its neighbour"},
-            "kernels_ms_alone": {"launch": float(np.mean(sync_k2)) if sync_k2 else None, "mode": lone_mode,
-                                 "note": "a launch that has the GPU to itself (the warm-up steps); the engine picks the mode, mtr_set_overlapped_launches"},
+            "kernels_ms_alone": {"launch": float(np.mean([k["k2_units"] for k in sync_k2])) if sync_k2 else None, "phases": phase_ms_alone, "mode": lone_mode,
+                                 "note": "a launch that has the GPU to itself (the warm-up steps)"},
             "kernels_mode_timed": eng.last_mode(),
             "work_per_launch": {k: cnt[k] for k in ("dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_dp_cells", "memo_hits", "memo_cells",
                                                     "kmer_tables", "tables_skipped", "kmer_lookups", "ranges_executed", "records", "traceback_steps")},
-            "roofline": {"bound": "hbm", "kernel": "mtr_k_reads", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": prof_tag,
-                         "algorithmic_bytes_per_launch": b_alg,
-                         "valu": {"achieved_lane_ops_per_s": valu_ops, "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                                  "frac": valu_ops / VALU_PEAK_LANE_OPS, "cells_per_launch": cells, "ops_per_cell": OPS_PER_CELL},
+            "reference_work_per_launch": {k: ref_cnt[k] for k in ("dp_calls", "dp_cells", "revise_dp_calls", "revise_dp_cells", "memo_hits", "memo_cells", "ranges_executed", "records")},
+            "roofline": {"bound": "valu-issue",
+                         "kernel": "one launch = the staged chain (mtr_k1_ranges, mtr_k_walks, mtr_k_walks_k, mtr_k_gather, mtr_k_dp2_quads, mtr_k_dp2_waves, "
+                                   "mtr_k_select, mtr_k_revise_quads, mtr_k_finish, mtr_k_replay); dominant kernels: mtr_k_revise_quads and mtr_k_dp2_quads (kernels_ms.phases)",
+                         "achieved": valu_ops / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s",
+                         "frac": valu_ops / VALU_PEAK_LANE_OPS,
+                         "frac_by_step": cells * OPS_PER_CELL / step_s / VALU_PEAK_LANE_OPS,
+                         "cells_per_launch": cells, "ops_per_cell": OPS_PER_CELL,
                          "issue": issue,
-                         "note": "not HBM-bound: row-serial integer max-plus recurrence (instruction issue + cross-lane scan latency); cells = the reference's DP "
-                                 "cells, of which memo_cells were answered without a DP; issue = VALU issue utilisation (SQ_INSTS_VALU x 2 cycles / SIMD-cycles of the launch)"},
+                         "hbm": {"achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+                                 "frac_by_step": b_alg / step_s / 1e9 / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_launch": b_alg, "spilled": "every DP of the reference is counted as spilled (SURVEY.md 8d's upper figure)"},
+                         "traffic": traffic, "traffic_source": prof_tag,
+                         "note": "bound by VALU instruction issue: row-serial integer max-plus recurrence; cells = the reference's DP cells, of which memo_cells were "
+                                 "answered without a DP; issue = VALU issue utilisation (SQ_INSTS_VALU x 2 cycles / SIMD-cycles of the launch) of the profiled build"},
         }
         if world == 1:
             out["value_kernel"] = n_job * a.steps / dt_kernel

@@ -39,7 +39,7 @@ extern "C" {
 /* Longest read the hot path takes: the reference's buffers hold L + 2r entries with r = L/10 random flank bases
  * (handle_one_read.c:194-204), so beyond L + 2r = MAX_INPUT_LENGTH it writes out of bounds; uploads refuse such reads. */
 #define MTR_MAX_READ_LENGTH 833333
-#define MTR_ABI_VERSION 2
+#define MTR_ABI_VERSION 3
 
 typedef enum {
     MTR_OK = 0,
@@ -101,12 +101,6 @@ mtr_status mtr_run_resident(mtr_ctx *ctx);
  * one batch with the start of the next (bench.py pipelines its steps this way). */
 mtr_status mtr_run_resident_async(mtr_ctx *ctx);
 mtr_status mtr_wait(mtr_ctx *ctx);
-/* The library has two ways to run a batch of more than a few thousand reads (same records): a chain of kernels over the
- * whole batch, fastest when the launch has the GPU to itself, and one kernel with a wavefront per read, fastest when the
- * launches of several contexts overlap.  By default a launch decides by whether another context of the device has a launch
- * that has not been waited for.  A host pipeline that WILL overlap launches says so here (1) before its first one, so that
- * the first launch already is of the overlapping kind; 0 restores the default. */
-mtr_status mtr_set_overlapped_launches(mtr_ctx *ctx, int32_t overlapped);
 mtr_status mtr_fetch_results(mtr_ctx *ctx, mtr_record **out_records, int32_t **out_counts, int64_t *out_total);
 /* A failed run (mtr_wait returned an error) is remembered: fetch / export / alignments of that batch return the same
  * status instead of partial records.  After MTR_ERR_DP_TOO_LARGE the reads BEFORE the failing one (input order) are
@@ -208,8 +202,11 @@ mtr_status mtr_export_records_device(mtr_ctx *ctx, void *d_dst, int64_t capacity
 mtr_status mtr_alignments(mtr_ctx *ctx, int32_t n, const int32_t *read_idx, const mtr_record *records,
                           uint8_t **out_ops, int64_t **out_off, int32_t **out_end);
 
-/* Per-kernel device time of the last mtr_run_resident()/mtr_process_batch(), measured with HIP events
- * on the stream the kernels were launched on.  Kernel ids: 0 = ranges (K1), 1 = units+DP (K2). */
+/* Device time of the last mtr_run_resident()/mtr_process_batch(), measured with HIP events on the stream the kernels were
+ * launched on.  Ids: 0 = the range kernel when it runs alone (test entry points), 1 = the whole launch; and the phases of the
+ * staged chain (launches = 0 for a batch the per-read kernel ran): 2 = candidate ranges, 3 = unit search (k-mer tables, seeds, walks),
+ * 4 = two-parameter alignments, 5 = selection, 6 = revisions, 7 = comparison over k + replay of the sequential range loop. */
+#define MTR_N_KERNEL_TIMES 8
 typedef struct mtr_kernel_time { float ms; int32_t launches; } mtr_kernel_time;
 mtr_status mtr_get_kernel_times(const mtr_ctx *ctx, mtr_kernel_time *out, int32_t n_kernels);
 

@@ -29,7 +29,7 @@ COUNTER_NAMES = ["dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_d
 EXPORTS = ["mtr_create", "mtr_destroy", "mtr_last_error", "mtr_abi_version", "mtr_process_batch", "mtr_free_results",
            "mtr_upload_batch", "mtr_run_resident", "mtr_fetch_results", "mtr_get_kernel_times", "mtr_get_counters",
            "mtr_test_ranges", "mtr_test_wrap_dp", "mtr_test_last_mode", "mtr_set_trace", "mtr_get_trace", "mtr_export_records_device",
-           "mtr_run_resident_async", "mtr_wait", "mtr_set_overlapped_launches", "mtr_alignments",
+           "mtr_run_resident_async", "mtr_wait", "mtr_alignments",
            "mtr_file_state_create", "mtr_file_state_destroy", "mtr_upload_batch_in_file", "mtr_file_state_skip",
            "mtr_get_bases_after_read", "mtr_upload_batch_packed", "mtr_fetch_results_packed", "mtr_export_packed_device",
            "mtr_unpack_records", "mtr_pack_records", "mtr_get_first_failed_read"]
@@ -140,8 +140,6 @@ def load_library(path: str = LIB_PATH):
     lib.mtr_wait.restype = C.c_int
     lib.mtr_test_last_mode.argtypes = [C.c_void_p]
     lib.mtr_test_last_mode.restype = C.c_int32
-    lib.mtr_set_overlapped_launches.argtypes = [C.c_void_p, C.c_int32]
-    lib.mtr_set_overlapped_launches.restype = C.c_int
     lib.mtr_fetch_results.argtypes = [C.c_void_p, P(P(CRecord)), P(P(C.c_int32)), P(C.c_int64)]
     lib.mtr_fetch_results.restype = C.c_int
     lib.mtr_get_kernel_times.argtypes = [C.c_void_p, P(CKernelTime), C.c_int32]
@@ -246,11 +244,7 @@ class Engine:
 
     def last_mode(self) -> str:
         """how the last launch ran (mtr_test_last_mode)"""
-        return {0: "per-read kernel", 1: "range-parallel", 2: "staged chain"}.get(int(self.lib.mtr_test_last_mode(self.h)), "?")
-
-    def set_overlapped(self, on: bool = True):
-        """tell the engine that launches of several contexts will overlap on this device (mtr_set_overlapped_launches)"""
-        self._check(self.lib.mtr_set_overlapped_launches(self.h, 1 if on else 0), "mtr_set_overlapped_launches")
+        return {0: "per-read kernel", 2: "staged chain"}.get(int(self.lib.mtr_test_last_mode(self.h)), "?")
 
     def fetch(self) -> List[List[Record]]:
         recs = C.POINTER(CRecord)()
@@ -358,9 +352,13 @@ class Engine:
 
     # ---- measurements ------------------------------------------------------------------------------------
     def kernel_times_ms(self):
-        kt = (CKernelTime * 2)()
-        self._check(self.lib.mtr_get_kernel_times(self.h, kt, 2), "mtr_get_kernel_times")
-        return {"k1_ranges": float(kt[0].ms), "k2_units": float(kt[1].ms)}
+        kt = (CKernelTime * 8)()
+        self._check(self.lib.mtr_get_kernel_times(self.h, kt, 8), "mtr_get_kernel_times")
+        out = {"k1_ranges": float(kt[0].ms), "k2_units": float(kt[1].ms)}
+        for i, name in enumerate(("ranges", "unit_search", "alignments", "selection", "revisions", "finish_replay")):
+            if kt[2 + i].launches:
+                out["chain_" + name] = float(kt[2 + i].ms)
+        return out
 
     def counters(self):
         c = (C.c_int64 * len(COUNTER_NAMES))()

@@ -7,8 +7,9 @@
 //   ranges   per read a slice [r_off, r_off + L/2+64) of start/end/w/DI-bits written by the range phase, read by the unit phase
 //   records  per read max_rec fixed slots written by the unit phase, compacted on the device before the copy back
 //   scratch  one slice per resident wavefront, sized for the longest read of the batch (K1Layout/K2Layout)
-// Two ways through a batch (mtr_run_resident): one wavefront per read (mtr_k_reads), or, for batches that cannot fill
-// the chip, the range-parallel mode (launch_split: ranges kernel(s), one work item per range, replay).
+// A batch runs as the staged chain (launch_staged, k3_staged.hip.inc); the per-read kernel (launch_reads: one wavefront per read,
+// the reference's sequential range loop) takes a batch that outgrew one of the chain's buffers, reads that found more records than
+// their slots, and MTR_STAGED=0.
 // Batch buffers are kept between batches and only grow.
 // There is no CPU path: every entry point needs the HIP device the context was created on.
 #include <hip/hip_runtime.h>
@@ -59,6 +60,7 @@ struct mtr_ctx {
     int device = 0, manhattan = 1; float min_ratio = 0.6f;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t ev_ph[MTR_N_KERNEL_TIMES] = {};     // phase boundaries of the staged chain (ev_ph[p] = end of phase p, p = 2..7)
     std::string err;
     int n_cu = 256;
     uint8_t *d_mt = nullptr;
@@ -66,6 +68,8 @@ struct mtr_ctx {
     int n_reads = 0, Lmax = 0;
     std::vector<int32_t> lens; std::vector<int64_t> roff;
     long long packed_words = 0;
+    long long st_last_arena_cap = 0;
+    int64_t st_arena_per_base = 256;   // bytes of candidate arena per read base reserved by the staged chain (x 4 after an overflow)
     uint32_t *d_packed = nullptr; int64_t *d_woff = nullptr; int32_t *d_lens = nullptr, *d_order = nullptr;
     int64_t *d_roff = nullptr; int32_t *d_rcount = nullptr, *d_rstart = nullptr, *d_rend = nullptr, *d_rw = nullptr; uint64_t *d_rdi = nullptr;
     int64_t total_rcap = 0;
@@ -76,8 +80,8 @@ struct mtr_ctx {
     uint8_t *d_scratch = nullptr; size_t scratch_bytes = 0;
     int32_t *d_trace = nullptr; unsigned *d_trace_n = nullptr; int trace_cap = 0;
     // range-parallel mode (small batches): work items = (read, range), parked candidate records
-    int32_t *d_item_read = nullptr, *d_item_idx = nullptr, *d_cand_flag = nullptr; int64_t *d_item_off = nullptr; DevRecord *d_cand = nullptr;
-    int64_t item_cap = 0; bool last_split = false, last_staged = false;
+    int32_t *d_item_read = nullptr, *d_item_idx = nullptr; int64_t *d_item_off = nullptr;
+    int64_t item_cap = 0; bool last_staged = false;
     // staged mode (k3_staged.hip.inc): fixed-capacity buffers of one batch
     uint8_t *d_st_arena = nullptr; int64_t *d_st_kc = nullptr; StDpItem *d_st_dp = nullptr;
     unsigned *d_st_bincnt = nullptr; int32_t *d_st_dpbin = nullptr, *d_st_dprank = nullptr, *d_st_binstart = nullptr, *d_st_sorted = nullptr, *d_st_classwave = nullptr;
@@ -94,10 +98,9 @@ struct mtr_ctx {
     // file-order mode (mtr_upload_batch_in_file): per read the stale tail of the reference's inputString_w_rand
     bool file_order = false; uint16_t *d_tail = nullptr; int64_t *d_tail_off = nullptr;
     std::vector<uint8_t> after;                        // 2 per read: orgInputString[L], [L+1] (zeros unless file-order)
-    mtr_kernel_time kt[2] = { { 0, 0 }, { 0, 0 } };
+    mtr_kernel_time kt[MTR_N_KERNEL_TIMES] = {};
     unsigned long long counters[CNT_N] = { 0 };
     bool ran = false, pending = false;
-    bool overlapped = false;           // mtr_set_overlapped_launches
     mtr_status run_status = MTR_OK;                    // of the last run: latched until the next upload
     int32_t first_failed = -1; int32_t *d_fail_read = nullptr;   // first read (input order) whose DP exceeded WrapDPsize
     // wire-form fetch: per-read byte sizes / offsets on the device, pinned staging on the host (grow-only)
@@ -114,13 +117,6 @@ struct mtr_ctx {
 static std::mutex g_mt_mu;
 static struct { uint8_t *d = nullptr; int refs = 0; } g_mt[64];
 // launches the host has not waited for, per device (the mode policy asks whether launches overlap, use_staged)
-static std::mutex g_pending_mu;
-static int g_pending[64];
-static void pending_add(int device, int d)
-{
-    std::lock_guard<std::mutex> g(g_pending_mu);
-    if (device >= 0 && device < 64) { g_pending[device] += d; if (g_pending[device] < 0) g_pending[device] = 0; }
-}
 static std::vector<uint8_t> g_mt_host;
 static const std::vector<uint8_t> &mt_host()
 {   // callers hold g_mt_mu
@@ -253,7 +249,7 @@ static void release_batch_buffers(mtr_ctx *ctx)
     dfree(ctx->d_roff); dfree(ctx->d_rcount); dfree(ctx->d_rstart); dfree(ctx->d_rend); dfree(ctx->d_rw); dfree(ctx->d_rdi);
     dfree(ctx->d_records); dfree(ctx->d_reccount); dfree(ctx->d_recoff); dfree(ctx->d_out);
     dfree(ctx->d_ovf_records); dfree(ctx->d_rec_base); dfree(ctx->d_ovf_order); dfree(ctx->d_src);
-    dfree(ctx->d_item_read); dfree(ctx->d_item_idx); dfree(ctx->d_cand_flag); dfree(ctx->d_item_off); dfree(ctx->d_cand); ctx->item_cap = 0;
+    dfree(ctx->d_item_read); dfree(ctx->d_item_idx); dfree(ctx->d_item_off); ctx->item_cap = 0;
     dfree(ctx->d_tail); dfree(ctx->d_tail_off);
     dfree(ctx->d_st_arena); dfree(ctx->d_st_kc); dfree(ctx->d_st_dp); dfree(ctx->d_st_bincnt); dfree(ctx->d_st_dpbin); dfree(ctx->d_st_dprank);
     dfree(ctx->d_st_binstart); dfree(ctx->d_st_sorted); dfree(ctx->d_st_classwave); dfree(ctx->d_st_cand); dfree(ctx->d_st_flag); dfree(ctx->d_st_scalars); dfree(ctx->d_st_wv); dfree(ctx->d_st_res); dfree(ctx->d_st_items); dfree(ctx->d_st_cont); dfree(ctx->d_st_rev);
@@ -296,6 +292,7 @@ extern "C" mtr_status mtr_create(int device, int manhattan, float min_match_rati
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 4; i++) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
+    for (int i = 2; ok && i < MTR_N_KERNEL_TIMES; i++) ok = hipEventCreate(&ctx->ev_ph[i]) == hipSuccess;
     ok = ok && hipMalloc(&ctx->d_status, sizeof(int32_t)) == hipSuccess;
     ok = ok && hipMalloc(&ctx->d_work, sizeof(unsigned)) == hipSuccess;
     ok = ok && hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * CNT_N) == hipSuccess;
@@ -321,7 +318,7 @@ extern "C" void mtr_destroy(mtr_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->pending) { (void)hipStreamSynchronize(ctx->stream); ctx->pending = false; pending_add(ctx->device, -1); }
+    if (ctx->pending) { (void)hipStreamSynchronize(ctx->stream); ctx->pending = false; }
     release_batch_buffers(ctx);
     if (ctx->d_mt) {
         std::lock_guard<std::mutex> lk(g_mt_mu);
@@ -331,6 +328,7 @@ extern "C" void mtr_destroy(mtr_ctx *ctx)
     dfree(ctx->d_status); dfree(ctx->d_work); dfree(ctx->d_counters); dfree(ctx->d_scratch);
     dfree(ctx->d_trace); dfree(ctx->d_trace_n); dfree(ctx->d_fail_read);
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < MTR_N_KERNEL_TIMES; i++) if (ctx->ev_ph[i]) (void)hipEventDestroy(ctx->ev_ph[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -575,8 +573,7 @@ static void k2_args(mtr_ctx *ctx, K2Args &a, size_t per_wave)
 
 // One wavefront per read as TWO kernels: the range kernel, then the unit kernel (mtr_k_units) with its work queue ordered by
 // the predicted cost of the reads (k3_staged.hip.inc: mtr_k_cost_*), each with its own scratch layout over the same
-// allocation.  The file-order mode always runs this way (its range kernel reads the stale tails); MTR_LPT=1 chooses it for
-// isolated semantics too.
+// allocation.  The file-order mode always runs this way (its range kernel reads the stale tails).
 static mtr_status launch_two_kernels(mtr_ctx *ctx)
 {
     const int n = ctx->n_reads;
@@ -610,12 +607,11 @@ static mtr_status launch_two_kernels(mtr_ctx *ctx)
     HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
     return MTR_OK;
 }
-static bool use_lpt() { const char *e = getenv("MTR_LPT"); return e && atoi(e) != 0; }
 
 // the per-read kernel: ranges (K1 code) and unit search / DP (K2 code) of a read by the same wavefront
 static mtr_status launch_reads(mtr_ctx *ctx)
 {
-    if (ctx->file_order || use_lpt()) return launch_two_kernels(ctx);
+    if (ctx->file_order) return launch_two_kernels(ctx);
     K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
     const size_t per_wave = std::max(y1.total, y2.total);       // the two phases of a read use the arena one after the other
     size_t total = 0;
@@ -633,128 +629,46 @@ static mtr_status launch_reads(mtr_ctx *ctx)
     return MTR_OK;
 }
 
-// Range-parallel mode (k2_units.hip.inc): ranges kernel, then every (read, range) as a work item, then the replay of
-// the reference's sequential loop.  Chosen for batches that cannot fill the chip with one wavefront per read;
-// MTR_SPLIT=0/1 forces it off/on, MTR_SPLIT_MAX_READS moves the threshold.
-static bool use_split(const mtr_ctx *ctx)
-{
-    const char *e = getenv("MTR_SPLIT");
-    if (e) return atoi(e) != 0;
-    const char *m = getenv("MTR_SPLIT_MAX_READS");
-    // default: up to as many reads as there are resident wavefront slots (256 CUs x 16).  [measured] 4096 reads of 2 kb:
-    // 50 ms against 63 ms with one wavefront per read; 10 000 reads: 123 ms against 104 ms (the ranges kernel no longer
-    // overlaps the unit searches of other reads, and ~5 % more DP cells are computed for ranges the loop would have skipped)
-    const long max_reads = m ? atol(m) : (long)ctx->n_cu * 16;
-    return ctx->n_reads <= max_reads;
-}
-
-static mtr_status launch_split(mtr_ctx *ctx)
-{
-    const int n = ctx->n_reads;
-    HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
-    // few reads: one wavefront per (read, pass) in the range finder too (MTR_K1_PARTS_MAX_READS, default 256 reads:
-    // [measured] 1 read 7.6 -> 6.5 ms, 100 reads of 42 kb 403 -> 348 ms, but 1024 reads of 2 kb 40 -> 45 ms)
-    const long parts_max = getenv("MTR_K1_PARTS_MAX_READS") ? atol(getenv("MTR_K1_PARTS_MAX_READS")) : 256;
-    bool parts = n <= parts_max;
-    if (parts) {   // the per-(read, pass) form keeps scratch per READ: only while that stays within the scratch budget
-        size_t tot = 0;
-        parts = pick_waves(ctx, n, n, k1_layout(ctx->Lmax).total, &tot) == n;
-    }
-    mtr_status s = parts ? launch_k1_parts(ctx) : launch_k1(ctx); if (s != MTR_OK) return s;
-    std::vector<int32_t> rc((size_t)n);
-    HIPCHK(copy_sync(ctx, rc.data(), ctx->d_rcount, (size_t)n * 4, hipMemcpyDeviceToHost));       // waits for the ranges kernel
-    { mtr_status st = check_status(ctx); if (st != MTR_OK) return st; }
-    std::vector<int64_t> ioff((size_t)n + 1, 0);
-    for (int i = 0; i < n; i++) ioff[(size_t)i + 1] = ioff[(size_t)i] + rc[(size_t)i];
-    const int64_t items = ioff[(size_t)n];
-    if (items > 0x7fffffffLL) { ctx->err = "too many candidate ranges for the range-parallel mode"; return MTR_ERR_OVERFLOW; }
-    {
-        const size_t cap = (size_t)std::max<int64_t>(items, 1);
-        HIPCHK(ensure_dev(ctx, ctx->d_item_read, cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_item_idx, cap * 4));
-        HIPCHK(ensure_dev(ctx, ctx->d_cand_flag, cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_cand, cap * sizeof(DevRecord)));
-    }
-    std::vector<int32_t> iread((size_t)items), iidx((size_t)items);
-    {
-        int64_t p = 0;
-        for (int i = 0; i < n; i++) for (int t = 0; t < rc[(size_t)i]; t++, p++) { iread[(size_t)p] = i; iidx[(size_t)p] = t; }
-    }
-    HIPCHK(hipMemcpyAsync(ctx->d_item_read, iread.data(), (size_t)items * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_item_idx, iidx.data(), (size_t)items * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_item_off, ioff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    K2Layout y2 = k2_layout(ctx->Lmax);
-    size_t total = 0;
-    const int waves = pick_waves(ctx, (int)std::max<int64_t>(items, 1), waves_per_cu(), y2.total, &total);
-    s = ensure_scratch(ctx, total); if (s != MTR_OK) return s;
-    K2Args a{}; k2_args(ctx, a, y2.total);
-    SplitArgs sp{};
-    sp.item_read = ctx->d_item_read; sp.item_idx = ctx->d_item_idx; sp.item_off = ctx->d_item_off; sp.n_items = (int32_t)items;
-    sp.cand = ctx->d_cand; sp.cand_flag = ctx->d_cand_flag;
-    HIPCHK(hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->d_trace_n, 0, sizeof(unsigned), ctx->stream));
-    if (items > 0) {
-        hipLaunchKernelGGL(mtr_k_range_units, dim3((unsigned)waves), dim3(64), 0, ctx->stream, a, sp);
-        HIPCHK(hipGetLastError());
-    }
-    hipLaunchKernelGGL(mtr_k_replay, dim3((unsigned)std::min(n, 65535)), dim3(64), 0, ctx->stream, a, sp);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
-    return MTR_OK;
-}
-
 // Staged mode (k3_staged.hip.inc): ranges of every read, then every (read, range) through phase 1, then ALL two-parameter DPs
 // of the batch one per lane, then tracebacks + selection + revision per range, then the replay of the sequential loop.
 // One stream, no host round trip; every buffer has a capacity fixed here, and a batch that outgrows one is run again
 // by the per-read kernel (mtr_wait).  MTR_STAGED=0/1 forces it off/on.
 static int staged_quad_min(int64_t bases)
-{   // Alignments of units of up to 128 bases go four per wavefront (mtr_k_dp2_quads) in batches of at least 2 M bases (1 000 reads
+{   // Alignments of units of up to 128 bases go four per wavefront (mtr_k_dp2_quads) in batches of at least 8 M bases (4 000 reads
     // of 2 kb): smaller ones do not give every SIMD a wavefront that way, and then more wavefronts count for more than fewer
     // instructions per row.  The value is the number of such alignments the batch must have (checked on the device).
     // MTR_QUAD_MIN forces it (tests: 1 = always, 0 = never).
     const char *e = getenv("MTR_QUAD_MIN");
     if (e) { const long v = atol(e); return (int)(v < 0 ? 0 : (v > 0x7fffffff ? 0x7fffffff : v)); }
-    return bases >= 2000000 ? 1024 : 0;
-}
-static int pending_launches(int device)
-{
-    std::lock_guard<std::mutex> g(g_pending_mu);
-    return device >= 0 && device < 64 ? g_pending[device] : 0;
+    return bases >= 8000000 ? 1024 : 0;
 }
 static unsigned st_sum(const unsigned long long *cls) { unsigned t = 0; for (int c = 0; c < ST_NCLS; c++) t += (unsigned)cls[c * 32]; return t; }
-static bool use_staged(const mtr_ctx *ctx)
-{
+static bool use_staged(const mtr_ctx *)
+{   // [measured, round 3] the chain is the faster arrangement for every batch: a single 2 kb read 3.0 against 19 ms, 2 000 reads 19
+    // against 38 ms, 10 000 reads 61 against 75 ms for a launch that has the GPU to itself, and 49.5 against 52 ms a step when two
+    // contexts keep launches in flight (since the alignments and revisions of big batches run four per wavefront).  MTR_STAGED=0
+    // selects the per-read kernel (tests, diagnosis).
     const char *e = getenv("MTR_STAGED");
-    if (e) return atoi(e) != 0;
-    if (getenv("MTR_SPLIT")) return false;                 // an explicit choice between the two older modes
-    // [measured, two contexts keeping two launches in flight, reads/s at 1 000 / 2 000 / 3 000 / 4 000 / 6 000 / 10 000 reads of 2 kb per
-    // batch] staged 123 / 150 / 162 / 171 / 179 / 168 k, range-parallel 71 / 123 / 149 / 156 / 92 k, per-read kernel 52 / 94 / 130 / 155 /
-    // 185 / 193 k (tests/dev/thresholds.sh): the chain up to MTR_STAGED_MAX_READS (5 000) reads whatever the caller does, above that
-    // only for a launch that has the GPU to itself (below).
-    const char *m = getenv("MTR_STAGED_MAX_READS");
-    const long max_reads = m ? atol(m) : 5000;
-    if (ctx->n_reads <= max_reads) return true;
-    // Larger batches [measured after the work queues got sub-queues, 10 000 reads of 2 kb]: a launch that has the chip to itself
-    // takes 68-69 ms staged and 77-78 ms in the per-read kernel (no tail of slow reads); two contexts that keep two launches in
-    // flight run at 59.5 ms a step staged and 53.3 ms with the per-read kernel (the chain executes 10 % more instructions, and both
-    // are bound by instruction issue).  And the two do not mix: a per-read kernel launched behind a staged chain takes every
-    // wavefront slot as the chain's current kernel drains and holds them until it ends - it finishes first, the chain waits.
-    // So: staged unless launches overlap - the caller has said so (mtr_set_overlapped_launches: the command line on files of
-    // more than one batch, bench.py's timed steps), or another context's launch is waiting to be collected right now.
-    const char *l = getenv("MTR_STAGED_MAX_READS_LONE");
-    const long max_lone = l ? atol(l) : 12000;
-    return ctx->n_reads <= max_lone && !ctx->overlapped && pending_launches(ctx->device) == 0;
+    return e ? atoi(e) != 0 : true;
 }
 
+static mtr_status launch_reads(mtr_ctx *ctx);
 static mtr_status launch_staged(mtr_ctx *ctx)
 {
+    // a buffer of the chain that cannot be allocated (a GPU shared with other ranks or contexts): the per-read kernel takes the batch
+    bool alloc_failed = false;
+#define ST_ALLOC(call) do { if (!alloc_failed && (call) != hipSuccess) { (void)hipGetLastError(); alloc_failed = true; } } while (0)
     const int n = ctx->n_reads;
     int64_t sumL = 0; for (int i = 0; i < n; i++) sumL += ctx->lens[(size_t)i];
     StagedArgs s{};
     s.n_reads = n;
     size_t free_b = 0, tot_b = 0;
     if (hipMemGetInfo(&free_b, &tot_b) != hipSuccess) free_b = (size_t)16 << 30;
-    // parked candidates: 5 bytes per unit base; reads of long units (unit 200 x 200 copies: ~1 KB per candidate, ~20 per
-    // range) need two orders of magnitude more per base than 2 kb reads (8 bytes per base measured)
-    s.arena_cap = std::min<int64_t>(sumL * 1024 + (1 << 20), (int64_t)((double)free_b * 0.2) + (ctx->d_st_arena ? sumL * 1024 : 0));
+    // parked candidates: 5 bytes per unit base and slot; [measured] 2 kb reads use ~52 bytes per read base, reads of long units (unit
+    // 200 x 200 copies: ~1 KB per candidate, ~20 per range) several times that.  A batch that outgrows the arena is run once more with
+    // four times the room per base (mtr_wait), then by the per-read kernel.
+    const int64_t per_base = ctx->st_arena_per_base;
+    s.arena_cap = std::min<int64_t>(sumL * per_base + (16 << 20), (int64_t)((double)free_b * 0.2) + (ctx->d_st_arena ? sumL * per_base : 0));
     s.kc_cap = (int32_t)std::min<int64_t>(ctx->total_rcap, sumL / 8 + 4096);
     s.dp_cap = (int32_t)std::min<int64_t>(0x7fffff00, sumL / 8 + 4096);
     s.sorted_cap = s.dp_cap + 4 * ST_QCLASSES;
@@ -771,31 +685,31 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         test_cont_cap = cap("cont="); test_rev_cap = cap("rev=");
         s.sorted_cap = s.dp_cap + 4 * ST_QCLASSES;
     }
-    HIPCHK(ensure_dev(ctx, ctx->d_st_arena, (size_t)s.arena_cap));
-    HIPCHK(ensure_dev(ctx, ctx->d_st_kc, (size_t)s.kc_cap * 8)); HIPCHK(ensure_dev(ctx, ctx->d_st_dp, (size_t)s.dp_cap * sizeof(StDpItem)));
-    HIPCHK(ensure_dev(ctx, ctx->d_st_bincnt, (size_t)ST_NBINS * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_binstart, ((size_t)ST_NBINS + 1) * 4));
-    HIPCHK(ensure_dev(ctx, ctx->d_st_dpbin, (size_t)s.dp_cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_dprank, (size_t)s.dp_cap * 4));
-    HIPCHK(ensure_dev(ctx, ctx->d_st_sorted, (size_t)s.sorted_cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_classwave, 16 * 4));
-    HIPCHK(ensure_dev(ctx, ctx->d_st_cand, (size_t)s.cand_cap * sizeof(DevRecord))); HIPCHK(ensure_dev(ctx, ctx->d_st_flag, (size_t)std::max<int64_t>(ctx->total_rcap, 1) * 4));
+    ST_ALLOC(ensure_dev(ctx, ctx->d_st_arena, (size_t)s.arena_cap));
+    ST_ALLOC(ensure_dev(ctx, ctx->d_st_kc, (size_t)s.kc_cap * 8)); ST_ALLOC(ensure_dev(ctx, ctx->d_st_dp, (size_t)s.dp_cap * sizeof(StDpItem)));
+    ST_ALLOC(ensure_dev(ctx, ctx->d_st_bincnt, (size_t)ST_NBINS * 4)); ST_ALLOC(ensure_dev(ctx, ctx->d_st_binstart, ((size_t)ST_NBINS + 1) * 4));
+    ST_ALLOC(ensure_dev(ctx, ctx->d_st_dpbin, (size_t)s.dp_cap * 4)); ST_ALLOC(ensure_dev(ctx, ctx->d_st_dprank, (size_t)s.dp_cap * 4));
+    ST_ALLOC(ensure_dev(ctx, ctx->d_st_sorted, (size_t)s.sorted_cap * 4)); ST_ALLOC(ensure_dev(ctx, ctx->d_st_classwave, 16 * 4));
+    ST_ALLOC(ensure_dev(ctx, ctx->d_st_cand, (size_t)s.cand_cap * sizeof(DevRecord))); ST_ALLOC(ensure_dev(ctx, ctx->d_st_flag, (size_t)std::max<int64_t>(ctx->total_rcap, 1) * 4));
     // device scalars, each on a 256-byte line of its own (same-line atomics complete one after the other), then the work queues
     const size_t st_scalar_bytes = 64 * 256 + (size_t)ST_N_QUEUES * WQ_WORDS * 4;
-    HIPCHK(ensure_dev(ctx, ctx->d_st_scalars, st_scalar_bytes));
-    HIPCHK(ensure_dev(ctx, ctx->d_st_wv, (size_t)ST_NCLS * (size_t)s.dp_cap * 4)); HIPCHK(ensure_dev(ctx, ctx->d_st_res, (size_t)s.dp_cap * 16 * 4));
+    ST_ALLOC(ensure_dev(ctx, ctx->d_st_scalars, st_scalar_bytes));
+    ST_ALLOC(ensure_dev(ctx, ctx->d_st_wv, (size_t)ST_NCLS * (size_t)s.dp_cap * 4)); ST_ALLOC(ensure_dev(ctx, ctx->d_st_res, (size_t)s.dp_cap * 16 * 4));
     s.quad_min = staged_quad_min(sumL); s.wv_items = ctx->d_st_wv; s.dp_res = ctx->d_st_res;
     s.item_cap = (int32_t)std::min<int64_t>(0x7fffff00, ctx->total_rcap);
-    HIPCHK(ensure_dev(ctx, ctx->d_st_items, (size_t)std::max(s.item_cap, 1) * sizeof(int4)));
+    ST_ALLOC(ensure_dev(ctx, ctx->d_st_items, (size_t)std::max(s.item_cap, 1) * sizeof(int4)));
     s.item_tab = ctx->d_st_items;
     s.cont_cap = (int32_t)std::min<int64_t>(0x7fffff00, 2 * (int64_t)s.kc_cap);
     if (test_cont_cap >= 0) s.cont_cap = (int32_t)test_cont_cap;
-    HIPCHK(ensure_dev(ctx, ctx->d_st_cont, (size_t)ST_NCLS * (size_t)s.cont_cap * sizeof(int4)));
+    ST_ALLOC(ensure_dev(ctx, ctx->d_st_cont, (size_t)ST_NCLS * (size_t)s.cont_cap * sizeof(int4)));
     s.cont = ctx->d_st_cont;
-    s.k_first = getenv("MTR_STAGED_K_FIRST") ? std::max(1, atoi(getenv("MTR_STAGED_K_FIRST"))) : 3;
+    s.k_first = 3;
     s.rev_cap = test_rev_cap >= 0 ? (int32_t)test_rev_cap : s.kc_cap;
-    HIPCHK(ensure_dev(ctx, ctx->d_st_rev, (size_t)ST_NCLS * (size_t)s.rev_cap * 8));
+    ST_ALLOC(ensure_dev(ctx, ctx->d_st_rev, (size_t)ST_NCLS * (size_t)s.rev_cap * 8));
     s.rev_items = (long long *)ctx->d_st_rev;
     unsigned long long *sc = ctx->d_st_scalars;
     s.item_off = ctx->d_item_off; s.n_items = (int32_t *)(sc + 0 * 32);
-    s.arena = ctx->d_st_arena; s.arena_cur = sc + 1 * 32;
+    s.arena = ctx->d_st_arena; s.arena_cur = sc + 1 * 32; ctx->st_last_arena_cap = s.arena_cap;
     s.kc_items = (long long *)ctx->d_st_kc; s.n_kc = (unsigned *)(sc + 2 * 32);
     s.dp = ctx->d_st_dp; s.n_dp = (unsigned *)(sc + 3 * 32);
     s.bin_count = ctx->d_st_bincnt; s.dp_bin = ctx->d_st_dpbin; s.dp_rank = ctx->d_st_dprank;
@@ -806,7 +720,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
     // few reads: the range finder as one wavefront per (read, pass) over per-READ scratch (launch_k1_parts), as in the
     // range-parallel mode; the unit kernels then take their per-wavefront scratch behind it
-    const long parts_max = getenv("MTR_K1_PARTS_MAX_READS") ? atol(getenv("MTR_K1_PARTS_MAX_READS")) : 256;
+    const long parts_max = 256;
     bool parts = n <= parts_max;
     if (parts) { size_t tot = 0; parts = pick_waves(ctx, n, n, y1.total, &tot) == n; }
     const size_t per_wave = parts ? y2.total : std::max(y1.total, y2.total);
@@ -815,6 +729,12 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     const int waves1 = std::min(waves, n);
     size_t total_dp = 0;                                    // the per-DP kernel runs at twice the occupancy (no LDS table, 64 VGPRs)
     const int waves_dp = pick_waves(ctx, std::max(n * 8, ctx->n_cu * 32), 32, per_wave, &total_dp);
+    if (alloc_failed) {
+        DBG("staged chain: a buffer could not be allocated (%.1f GB free): the per-read kernel takes the batch", (double)free_b / 1e9);
+        dfree(ctx->d_st_arena); for (auto &c : ctx->caps) if (c.first == (void *)&ctx->d_st_arena) c.second = 0;
+        ctx->last_staged = false;
+        return launch_reads(ctx);
+    }
     mtr_status st = ensure_scratch(ctx, std::max(std::max(total, total_dp), parts ? (size_t)n * y1.total : (size_t)0)); if (st != MTR_OK) return st;
     K1Args a1{}; k1_args(ctx, a1, per_wave);
     K2Args a{}; k2_args(ctx, a, per_wave);
@@ -838,6 +758,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(mtr_k_item_table, dim3((unsigned)std::min(n, 4096)), dim3(256), 0, ctx->stream, a, s);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev_ph[2], ctx->stream));       // ranges
     {   // the walks align nothing: a scratch layout without the cell region, and as many wavefronts as the occupancy allows
         K2Args aw = a;
         aw.cells_cap = 256;
@@ -853,8 +774,9 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         hipLaunchKernelGGL(mtr_k_gather, dim3((unsigned)capped(ctx->n_cu * 16, 64)), dim3(64), 0, ctx->stream, a, s);
         HIPCHK(hipGetLastError());
     }
+    HIPCHK(hipEventRecord(ctx->ev_ph[3], ctx->stream));       // unit search (tables, seeds, walks) + the alignment items
     if (s.quad_min > 0) {
-        hipLaunchKernelGGL(mtr_k_qbins, dim3(1), dim3(1024), 0, ctx->stream, s);
+        hipLaunchKernelGGL(mtr_k_qbins, dim3(1), dim3(1024), 0, ctx->stream, s, 0);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(mtr_k_qscatter, dim3((unsigned)capped(512, 16384)), dim3(256), 0, ctx->stream, s);
         HIPCHK(hipGetLastError());
@@ -863,15 +785,25 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     }
     hipLaunchKernelGGL(mtr_k_dp2_waves, dim3((unsigned)capped(waves_dp, 16)), dim3(64), 0, ctx->stream, a, s);
     HIPCHK(hipGetLastError());
+    if (s.quad_min > 0) HIPCHK(hipMemsetAsync(ctx->d_st_bincnt, 0, (size_t)ST_NBINS * 4, ctx->stream));     // the revisions are sorted next
+    HIPCHK(hipEventRecord(ctx->ev_ph[4], ctx->stream));       // two-parameter alignments
     hipLaunchKernelGGL(mtr_k_select, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(mtr_k_revise, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
+    HIPCHK(hipEventRecord(ctx->ev_ph[5], ctx->stream));       // selection
+    if (s.quad_min > 0) {
+        // four revisions per wavefront: mtr_k_select has binned them (the alignments' sort buffers are free again)
+        hipLaunchKernelGGL(mtr_k_qbins, dim3(1), dim3(1024), 0, ctx->stream, s, 1);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(mtr_k_rscatter, dim3((unsigned)capped(512, 16384)), dim3(256), 0, ctx->stream, s);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(mtr_k_revise_quads, dim3((unsigned)capped(waves, 256)), dim3(64), 0, ctx->stream, a, s);
+    } else hipLaunchKernelGGL(mtr_k_revise, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev_ph[6], ctx->stream));       // revisions
     hipLaunchKernelGGL(mtr_k_finish, dim3((unsigned)capped(ctx->n_cu * 16, 64)), dim3(64), 0, ctx->stream, a, s);
     HIPCHK(hipGetLastError());
     SplitArgs sp{};
-    sp.item_read = nullptr; sp.item_idx = nullptr; sp.item_off = ctx->d_item_off; sp.n_items = 0;
-    sp.cand = ctx->d_st_cand; sp.cand_flag = ctx->d_st_flag; sp.indirect = 1;
+    sp.item_off = ctx->d_item_off; sp.cand = ctx->d_st_cand; sp.cand_flag = ctx->d_st_flag;
     hipLaunchKernelGGL(mtr_k_replay, dim3((unsigned)std::min(n, 65535)), dim3(64), 0, ctx->stream, a, sp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
@@ -917,34 +849,33 @@ extern "C" mtr_status mtr_run_resident_async(mtr_ctx *ctx)
     HIPCHK(hipMemsetAsync(ctx->d_fail_read, 0x7f, 4, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
     ctx->last_staged = use_staged(ctx);
-    ctx->last_split = !ctx->last_staged && use_split(ctx);
-    DBG("launch of %d reads: %s", ctx->n_reads, ctx->last_staged ? "staged chain" : ctx->last_split ? "range-parallel" : "per-read kernel");
-    mtr_status s = ctx->last_staged ? launch_staged(ctx) : ctx->last_split ? launch_split(ctx) : launch_reads(ctx); if (s != MTR_OK) return s;
+    DBG("launch of %d reads: %s", ctx->n_reads, ctx->last_staged ? "staged chain" : "per-read kernel");
+    mtr_status s = ctx->last_staged ? launch_staged(ctx) : launch_reads(ctx); if (s != MTR_OK) return s;
     ctx->pending = true;
-    pending_add(ctx->device, 1);
     return MTR_OK;
 }
 
-extern "C" int32_t mtr_test_last_mode(const mtr_ctx *ctx) { return !ctx ? -1 : ctx->last_staged ? 2 : ctx->last_split ? 1 : 0; }
-
-extern "C" mtr_status mtr_set_overlapped_launches(mtr_ctx *ctx, int32_t overlapped)
-{
-    if (!ctx) return MTR_ERR_BAD_ARG;
-    ctx->overlapped = overlapped != 0;
-    return MTR_OK;
-}
+extern "C" int32_t mtr_test_last_mode(const mtr_ctx *ctx) { return !ctx ? -1 : ctx->last_staged ? 2 : 0; }
 
 extern "C" mtr_status mtr_wait(mtr_ctx *ctx)
 {
     if (!ctx) return MTR_ERR_BAD_ARG;
     if (!ctx->pending) return ctx->run_status;
     HIPCHK(hipSetDevice(ctx->device));
-    pending_add(ctx->device, -1);
     ctx->pending = false; ctx->ran = false; ctx->run_status = MTR_ERR_HIP;   // until everything below succeeded
     HIPCHK(hipStreamSynchronize(ctx->stream));
     float ms = 0;
     ctx->kt[0].ms = 0; ctx->kt[0].launches = 0;                // K1 runs inside the per-read kernel
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->kt[1].ms = ms; ctx->kt[1].launches = 1;
+    for (int p = 2; p < MTR_N_KERNEL_TIMES; p++) { ctx->kt[p].ms = 0; ctx->kt[p].launches = 0; }
+    if (ctx->last_staged) {
+        hipEvent_t prev = ctx->ev[2];
+        for (int p = 2; p < MTR_N_KERNEL_TIMES; p++) {
+            hipEvent_t cur = p == MTR_N_KERNEL_TIMES - 1 ? ctx->ev[3] : ctx->ev_ph[p];
+            HIPCHK(hipEventElapsedTime(&ms, prev, cur)); ctx->kt[p].ms = ms; ctx->kt[p].launches = 1;
+            prev = cur;
+        }
+    }
     HIPCHK(copy_sync(ctx, ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
     mtr_status st = check_status(ctx);
     if (ctx->last_staged && dbg()) {
@@ -958,17 +889,52 @@ extern "C" mtr_status mtr_wait(mtr_ctx *ctx)
         int32_t dst = 0;
         HIPCHK(copy_sync(ctx, &dst, ctx->d_status, 4, hipMemcpyDeviceToHost));
         if (dst == DEV_ERR_STAGED_OVERFLOW) {
-            DBG("staged mode: buffer overflow, running the batch with the per-read kernel");
-            ctx->last_staged = false;
+            unsigned long long used = 0;
+            (void)copy_sync(ctx, &used, ctx->d_st_scalars + 1 * 32, sizeof used, hipMemcpyDeviceToHost);
+            const bool arena_full = ctx->d_st_arena && used > ctx->st_last_arena_cap && ctx->st_arena_per_base < 1024 && !getenv("MTR_TEST_STAGED_CAPS");
+            if (arena_full) ctx->st_arena_per_base *= 4;
+            DBG("staged chain: a buffer overflowed (candidate arena %.1f of %.1f MB): %s", (double)used / 1e6, (double)ctx->st_last_arena_cap / 1e6,
+                arena_full ? "once more with four times the arena per base" : "running the batch with the per-read kernel");
+            ctx->last_staged = arena_full;
             HIPCHK(hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
             HIPCHK(hipMemsetAsync(ctx->d_fail_read, 0x7f, 4, ctx->stream));
             HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
-            { mtr_status ls = launch_reads(ctx); if (ls != MTR_OK) { ctx->run_status = ls; return ls; } }
+            { mtr_status ls = arena_full ? launch_staged(ctx) : launch_reads(ctx); if (ls != MTR_OK) { ctx->run_status = ls; return ls; } }
+            if (arena_full) {
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                int32_t d2 = 0;
+                HIPCHK(copy_sync(ctx, &d2, ctx->d_status, 4, hipMemcpyDeviceToHost));
+                if (d2 == DEV_ERR_STAGED_OVERFLOW) {
+                    DBG("staged chain: overflow again, running the batch with the per-read kernel");
+                    ctx->last_staged = false;
+                    HIPCHK(hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+                    HIPCHK(hipMemsetAsync(ctx->d_fail_read, 0x7f, 4, ctx->stream));
+                    HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
+                    { mtr_status ls = launch_reads(ctx); if (ls != MTR_OK) { ctx->run_status = ls; return ls; } }
+                }
+            }
             HIPCHK(hipStreamSynchronize(ctx->stream));
             HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->kt[1].ms += ms; ctx->kt[1].launches = 2;
+            for (int p = 2; p < MTR_N_KERNEL_TIMES; p++) { ctx->kt[p].ms = 0; ctx->kt[p].launches = 0; }
             HIPCHK(copy_sync(ctx, ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
             st = check_status(ctx);
         }
+    }
+    if (st == MTR_ERR_DP_TOO_LARGE && ctx->last_staged) {
+        // The chain aligns the candidates of EVERY range, also of ranges the reference's sequential loop would have removed after an
+        // accepted repeat: a matrix beyond WrapDPsize in such a range is not the reference's failure.  The per-read kernel runs
+        // the reference's own loop: its verdict (and its first failing read) counts.
+        DBG("staged chain: a DP exceeded WrapDPsize; the per-read kernel decides whether the reference's loop reaches it");
+        ctx->last_staged = false;
+        HIPCHK(hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->d_fail_read, 0x7f, 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
+        { mtr_status ls = launch_reads(ctx); if (ls != MTR_OK) { ctx->run_status = ls; return ls; } }
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->kt[1].ms += ms; ctx->kt[1].launches = 2;
+        for (int p = 2; p < MTR_N_KERNEL_TIMES; p++) { ctx->kt[p].ms = 0; ctx->kt[p].launches = 0; }
+        HIPCHK(copy_sync(ctx, ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
+        st = check_status(ctx);
     }
     if (st == MTR_ERR_DP_TOO_LARGE) {
         int32_t fr = -1;
@@ -1264,7 +1230,7 @@ extern "C" mtr_status mtr_get_bases_after_read(const mtr_ctx *ctx, int32_t read_
 extern "C" mtr_status mtr_get_kernel_times(const mtr_ctx *ctx, mtr_kernel_time *out, int32_t n)
 {
     if (!ctx || !out) return MTR_ERR_BAD_ARG;
-    for (int i = 0; i < n && i < 2; i++) out[i] = ctx->kt[i];
+    for (int i = 0; i < n && i < MTR_N_KERNEL_TIMES; i++) out[i] = ctx->kt[i];
     return MTR_OK;
 }
 

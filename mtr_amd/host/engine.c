@@ -44,7 +44,6 @@ int mtrh_engine_load(mtrh_engine *e, const char *lib_path, char *err, size_t err
     BIND(run_async, "mtr_run_resident_async"); BIND(wait, "mtr_wait"); BIND(fetch_packed, "mtr_fetch_results_packed");
     BIND(first_failed, "mtr_get_first_failed_read"); BIND(alignments, "mtr_alignments"); BIND(bases_after, "mtr_get_bases_after_read");
     BIND(kernel_times, "mtr_get_kernel_times"); BIND(counters, "mtr_get_counters");
-    *(void **)(&e->set_overlapped) = dlsym(e->dl, "mtr_set_overlapped_launches");
     BIND(fs_create, "mtr_file_state_create"); BIND(fs_destroy, "mtr_file_state_destroy"); BIND(fs_skip, "mtr_file_state_skip");
     __typeof__(mtr_abi_version) *ver = NULL;
     *(void **)(&ver) = dlsym(e->dl, "mtr_abi_version");

@@ -37,7 +37,6 @@ typedef struct mtrh_engine {
     __typeof__(mtr_alignments) *alignments;
     __typeof__(mtr_get_bases_after_read) *bases_after;
     __typeof__(mtr_get_kernel_times) *kernel_times;
-    __typeof__(mtr_set_overlapped_launches) *set_overlapped;      /* optional: NULL if the library does not export it */
     __typeof__(mtr_get_counters) *counters;
     __typeof__(mtr_file_state_create) *fs_create;
     __typeof__(mtr_file_state_destroy) *fs_destroy;

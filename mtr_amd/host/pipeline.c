@@ -302,11 +302,6 @@ static void *device_main(void *arg)
             if (!*pc) {
                 st = r->eng.create(r->o.device, r->o.manhattan, r->o.min_match_ratio, pc);
                 mtrh_stamp(k == 0 ? "first device context created" : "second device context created");
-                /* more input behind this batch: launches will overlap (the engine picks its kernel mode by that, mtr_hip.h) */
-                if (st == MTR_OK && (r->overlap || nx != NULL || idx + 1 < r->n_list)) {
-                    r->overlap = 1;
-                    if (r->eng.set_overlapped) (void)r->eng.set_overlapped(*pc, 1);
-                }
                 if (st != MTR_OK) {
                     char m[256];
                     snprintf(m, sizeof m, "fatal error: no usable HIP device (mtr_create returned %d); this build has no CPU path", (int)st);

@@ -89,11 +89,75 @@ __global__ __launch_bounds__(64, WPS) void k_quad(const uint32_t *pk, const uint
     }
     if (lane_id() == 0) out[blockIdx.x * 32 + 7] = acc;
 }
+
+#ifndef SG
+#define SG 5
+#define SMM 1
+#define SD 1
+#endif
+__global__ __launch_bounds__(64, WPS) void k_single1p(const uint32_t *pk, const uint8_t *units, const Job *jobs, int reps, uint8_t *cells, size_t cells_per_job, int *out, int fast)
+{
+    int acc = 0;
+    for (int r = 0; r < reps; r++) {
+        for (int g = 0; g < 4; g++) {
+            const int ji = blockIdx.x * 4 + g;
+            const Job jb = jobs[ji];
+            const int rd = uni(jb.read), base = uni(jb.base), rows = uni(jb.rows), U = uni(jb.U);
+            int bv, bi, bj;
+            uint8_t *codes = cells + (size_t)ji * cells_per_job;
+            const uint32_t *p = pk + (size_t)rd * 256; const uint8_t *u = units + (size_t)rd * 512;
+            if (fast && U > 64) dp_forward_2c(p, base, rows, u, U, SG, SMM, SD, codes, (U + 1) >> 1, bv, bi, bj);
+            else if (U <= 64) dp_forward<1>(p, base, rows, u, U, SG, SMM, SD, codes, bv, bi, bj);
+            else dp_forward<2>(p, base, rows, u, U, SG, SMM, SD, codes, bv, bi, bj);
+            if (lane_id() == 0 && r == 0) { out[ji * 8 + 0] = bv; out[ji * 8 + 1] = bi; out[ji * 8 + 2] = bj; out[ji * 8 + 3] = 0; out[ji * 8 + 4] = 0; out[ji * 8 + 5] = 0; }
+            acc += bv;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (lane_id() == 0) out[blockIdx.x * 32 + 7] = acc;
+}
+__global__ __launch_bounds__(64, WPS) void k_quad1p(const uint32_t *pk, const uint8_t *units, const Job *jobs, int reps, uint8_t *cells, size_t cells_per_job, int *out, int cq)
+{
+    int acc = 0;
+    for (int r = 0; r < reps; r++) {
+        DpQuad q; q.n = 4;
+        int maxrows = 0;
+        for (int g = 0; g < 4; g++) {
+            const Job jb = jobs[blockIdx.x * 4 + g];
+            const int rd = uni(jb.read);
+            q.pk[g] = pk + (size_t)rd * 256; q.wlim[g] = 256; q.base[g] = uni(jb.base); q.rows[g] = uni(jb.rows); q.U[g] = uni(jb.U);
+            q.unit[g] = units + (size_t)rd * 512;
+            maxrows = q.rows[g] > maxrows ? q.rows[g] : maxrows;
+        }
+        int best[4][3];
+        uint8_t *cb = cells + (size_t)blockIdx.x * 4 * cells_per_job;
+#ifdef ONLYC
+        dp_forward1p_g16<ONLYC>(q, SG, SMM, SD, cb, maxrows, best);
+#else
+        switch (cq) {
+        case 1: dp_forward1p_g16<1>(q, SG, SMM, SD, cb, maxrows, best); break;
+        case 2: dp_forward1p_g16<2>(q, SG, SMM, SD, cb, maxrows, best); break;
+        case 3: dp_forward1p_g16<3>(q, SG, SMM, SD, cb, maxrows, best); break;
+        case 4: dp_forward1p_g16<4>(q, SG, SMM, SD, cb, maxrows, best); break;
+        case 5: dp_forward1p_g16<5>(q, SG, SMM, SD, cb, maxrows, best); break;
+        case 6: dp_forward1p_g16<6>(q, SG, SMM, SD, cb, maxrows, best); break;
+        case 7: dp_forward1p_g16<7>(q, SG, SMM, SD, cb, maxrows, best); break;
+        default: dp_forward1p_g16<8>(q, SG, SMM, SD, cb, maxrows, best); break;
+        }
+#endif
+        if (lane_id() == 0 && r == 0) for (int g = 0; g < 4; g++) { for (int k = 0; k < 3; k++) out[(blockIdx.x * 4 + g) * 8 + k] = best[g][k]; for (int k = 3; k < 6; k++) out[(blockIdx.x * 4 + g) * 8 + k] = 0; }
+        acc += best[0][0];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane_id() == 0) out[blockIdx.x * 32 + 7] = acc;
+}
+static int canon(int f) { return (f & 8) ? 8 : !(f & 1) ? 0 : !(f & 2) ? 1 : !(f & 4) ? 3 : 7; }
 int main(int argc, char **argv)
 {
     const int U = argc > 1 ? atoi(argv[1]) : 100, rows = argc > 2 ? atoi(argv[2]) : 1000, reps = argc > 3 ? atoi(argv[3]) : 4;
     const int spreadU = argc > 4 ? atoi(argv[4]) : 0, spreadR = argc > 5 ? atoi(argv[5]) : 0;
-    const int cq = argc > 6 ? atoi(argv[6]) : (U + 15) / 16;
+    const int cq = argc > 6 && atoi(argv[6]) > 0 ? atoi(argv[6]) : (U + 15) / 16;
+    const int single = argc > 7 ? atoi(argv[7]) : 0;
     hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, 0);
     const int waves = pr.multiProcessorCount * 4 * WPS, njobs = waves * 4;
     std::vector<uint32_t> pk(1024 * 256); std::vector<uint8_t> un(1024 * 512);
@@ -125,7 +189,12 @@ int main(int argc, char **argv)
         float bestms = 1e9f;
         for (int it = 0; it < 3; it++) {
             (void)hipEventRecord(e0, 0);
-            if (which == 0) hipLaunchKernelGGL(k_single, dim3(waves), dim3(64), 0, 0, dpk, dun, dj, reps, dcA, cpj, doA);
+            if (single) {
+                if (which == 0) hipLaunchKernelGGL(k_single1p, dim3(waves), dim3(64), 0, 0, dpk, dun, dj, reps, dcA, cpj, doA, 0);
+                else if (which == 1) hipLaunchKernelGGL(k_single1p, dim3(waves), dim3(64), 0, 0, dpk, dun, dj, reps, dcA, cpj, doB, 1);
+                else hipLaunchKernelGGL(k_quad1p, dim3(waves), dim3(64), 0, 0, dpk, dun, dj, reps, dcB, cpj, doB, cq);
+            }
+            else if (which == 0) hipLaunchKernelGGL(k_single, dim3(waves), dim3(64), 0, 0, dpk, dun, dj, reps, dcA, cpj, doA);
             else if (which == 1) hipLaunchKernelGGL(k_single2c, dim3(waves), dim3(64), 0, 0, dpk, dun, dj, reps, dcA + 0, cpj, doB);
             else hipLaunchKernelGGL(k_quad, dim3(waves), dim3(64), 0, 0, dpk, dun, dj, reps, dcB, cpj, doB, cq);
             (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
@@ -136,12 +205,14 @@ int main(int argc, char **argv)
             bestms = 1e9f;
             for (int it = 0; it < 3; it++) {
                 (void)hipEventRecord(e0, 0);
-                hipLaunchKernelGGL(k_single2c, dim3(waves), dim3(64), 0, 0, dpk, dun, dj, reps, dcB, cpj, doB);
+                if (single) hipLaunchKernelGGL(k_single1p, dim3(waves), dim3(64), 0, 0, dpk, dun, dj, reps, dcB, cpj, doB, 1);
+                else hipLaunchKernelGGL(k_single2c, dim3(waves), dim3(64), 0, 0, dpk, dun, dj, reps, dcB, cpj, doB);
                 (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
                 float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (it > 0 && ms < bestms) bestms = ms;
             }
             // restore the reference cells
-            hipLaunchKernelGGL(k_single, dim3(waves), dim3(64), 0, 0, dpk, dun, dj, 1, dcA, cpj, doA);
+            if (single) hipLaunchKernelGGL(k_single1p, dim3(waves), dim3(64), 0, 0, dpk, dun, dj, 1, dcA, cpj, doA, 0);
+            else hipLaunchKernelGGL(k_single, dim3(waves), dim3(64), 0, 0, dpk, dun, dj, 1, dcA, cpj, doA);
             (void)hipDeviceSynchronize();
         }
         const char *nm = which == 0 ? "one per wavefront (dp_forward2p)" : which == 1 ? "one per wavefront (2 columns/lane)" : "four per wavefront (g16)";
@@ -162,7 +233,7 @@ int main(int argc, char **argv)
                 const uint8_t a = cA[(size_t)j * cpj + (size_t)(i - 1) * b.U + c];
                 const uint8_t q = cB[(size_t)w * 4 * cpj + ((size_t)(i - 1) * 4 + g) * 16 * cq + c];
                 checked++;
-                if (a != q) { if (bad_cells < 10) printf("cell differs job %d (U %d rows %d) row %d col %d: %02x vs %02x\n", j, b.U, b.rows, i, c + 1, a, q); bad_cells++; }
+                if (single ? (a != canon(q & 15)) : (a != q)) { if (bad_cells < 10) printf("cell differs job %d (U %d rows %d) row %d col %d: %02x vs %02x\n", j, b.U, b.rows, i, c + 1, a, q); bad_cells++; }
             }
     }
     printf("checked %ld cells: %ld differ; best cells differing: %ld\n", checked, bad_cells, bad_best);

@@ -24,7 +24,8 @@ def build_host():
 
 
 def build_replay():
-    if not os.path.exists(REPLAY_LIB) or os.path.getmtime(REPLAY_SRC) > os.path.getmtime(REPLAY_LIB):
+    hdr = os.path.join(ROOT, "include", "mtr_hip.h")
+    if not os.path.exists(REPLAY_LIB) or max(os.path.getmtime(REPLAY_SRC), os.path.getmtime(hdr)) > os.path.getmtime(REPLAY_LIB):
         subprocess.run(["gcc", "-std=gnu11", "-O2", "-Wall", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
                         "-o", REPLAY_LIB, REPLAY_SRC], check=True)
     return REPLAY_LIB

@@ -127,15 +127,15 @@ def test_pure_repeat_with_unit_250_to_256_as_longest_read(unit_len):
     orc = Oracle()
     want = [orc.process(c) for c in reads]
     orc.close()
-    for split in ("0", "1"):
-        os.environ["MTR_SPLIT"] = split
+    for staged in ("0", "1"):
+        os.environ["MTR_STAGED"] = staged
         try:
             e = mtr_amd.Engine()
             got = e.process(reads)
             e.close()
         finally:
-            del os.environ["MTR_SPLIT"]
-        assert [[tuple(r) for r in g] for g in got] == want, split
+            del os.environ["MTR_STAGED"]
+        assert [[tuple(r) for r in g] for g in got] == want, staged
     assert any(r[3] == unit_len for r in want[0])
 
 

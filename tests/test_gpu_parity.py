@@ -263,7 +263,7 @@ def test_read_of_the_maximum_length(eng, oracle):
 
 
 # ---- the kernel modes: same records as one wavefront per read -----------------------------------------------------------
-MODES = {"per_read": {"MTR_STAGED": "0", "MTR_SPLIT": "0"}, "range_parallel": {"MTR_STAGED": "0", "MTR_SPLIT": "1"},
+MODES = {"per_read": {"MTR_STAGED": "0"},
          "staged": {"MTR_STAGED": "1", "MTR_QUAD_MIN": "0"}, "staged_quads": {"MTR_STAGED": "1", "MTR_QUAD_MIN": "1"},
          "staged_overflow_arena": {"MTR_STAGED": "1", "MTR_TEST_STAGED_CAPS": "arena=200000"},
          "staged_overflow_kc": {"MTR_STAGED": "1", "MTR_TEST_STAGED_CAPS": "kc=40"},
@@ -275,8 +275,8 @@ MODES = {"per_read": {"MTR_STAGED": "0", "MTR_SPLIT": "0"}, "range_parallel": {"
 
 @pytest.mark.parametrize("mode", sorted(MODES))
 def test_kernel_modes_match_the_oracle(monkeypatch, oracle, mode):
-    """per_read: one wavefront per read (the reference's sequential range loop).  range_parallel: every candidate range its
-    own work item + replay of the sequential pruning.  staged: ranges -> walks -> every two-parameter DP its own work item
+    """per_read: one wavefront per read (the reference's sequential range loop; the fallback).  staged (the default arrangement):
+    ranges -> walks -> every two-parameter DP its own work item
     (one wavefront each; staged_quads: units of 17..128 bases four per wavefront whatever the batch size) -> selection/revision
     -> replay; staged_overflow_*: one of the chain's capacities far too small, so the library must fall back to the per-read kernel
     (the kernels behind the overflow must not walk the half-written work lists).  All must give the oracle's records."""
@@ -316,11 +316,11 @@ def test_unit_lengths_around_the_two_column_pass(monkeypatch, oracle, mode):
     e.close()
 
 
-def test_mode_policy_lone_and_overlapping_launches(monkeypatch):
-    """include/mtr_hip.h, mtr_set_overlapped_launches: a batch of more than a few thousand reads runs as the staged chain while
-    its launch has the GPU to itself, and in the per-read kernel when launches overlap - because another context's launch is
-    waiting to be collected, or because the caller has said so.  The records are the same in every case."""
-    for k in ("MTR_STAGED", "MTR_SPLIT", "MTR_STAGED_MAX_READS", "MTR_STAGED_MAX_READS_LONE", "MTR_LPT"):
+def test_the_chain_runs_every_batch_and_overlapping_launches_agree(monkeypatch):
+    """One arrangement: every batch runs as the staged chain, alone or while another context's launch is in flight (a big batch
+    with its alignments and revisions four per wavefront, a small one with one wavefront each); the per-read kernel only takes a
+    batch that outgrew a buffer, or MTR_STAGED=0.  The records are the same in every case."""
+    for k in ("MTR_STAGED", "MTR_QUAD_MIN"):
         monkeypatch.delenv(k, raising=False)
     reads = [c for _, c in synth.make_reads("headline2k", 5600, 17)]
     a, b = mtr_amd.Engine(), mtr_amd.Engine()
@@ -328,23 +328,24 @@ def test_mode_policy_lone_and_overlapping_launches(monkeypatch):
     a.run()
     assert a.last_mode() == "staged chain"
     lone = [[tuple(r) for r in g] for g in a.fetch()]
+    kt = a.kernel_times_ms()
+    assert all(kt.get("chain_" + p, 0) > 0 for p in ("ranges", "unit_search", "alignments", "revisions")), kt
     a.run_async(); b.run_async()                                   # b is launched while a's launch is pending
     a.wait(); b.wait()
-    assert a.last_mode() == "staged chain" and b.last_mode() != "staged chain"        # (the per-read kernel above MTR_STAGED_MAX_READS = 5 000 reads)
+    assert a.last_mode() == "staged chain" and b.last_mode() == "staged chain"
     assert [[tuple(r) for r in g] for g in b.fetch()] == lone
-    a.set_overlapped(True)
-    a.run()
-    assert a.last_mode() != "staged chain"
-    assert [[tuple(r) for r in g] for g in a.fetch()] == lone
-    a.set_overlapped(False)
     small = reads[:500]
-    a.upload(small); a.set_overlapped(True); a.run()
-    assert a.last_mode() == "staged chain"                          # small batches: the chain either way
+    a.upload(small); a.run()
+    assert a.last_mode() == "staged chain"
+    assert [[tuple(r) for r in g] for g in a.fetch()] == lone[:500]
+    monkeypatch.setenv("MTR_STAGED", "0")
+    a.run()
+    assert a.last_mode() == "per-read kernel"
     assert [[tuple(r) for r in g] for g in a.fetch()] == lone[:500]
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("mode", ["range_parallel", "staged", "staged_quads"])
+@pytest.mark.parametrize("mode", ["per_read", "staged", "staged_quads"])
 def test_kernel_modes_golden(monkeypatch, mode):
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)
@@ -415,17 +416,14 @@ def _file_order_case():
     return reads
 
 
-@pytest.mark.parametrize("manhattan,split", [(True, "0"), (True, "1"), (False, "0"), (False, "1"), (True, "staged"), (False, "staged")])
+@pytest.mark.parametrize("manhattan,split", [(True, "per_read"), (False, "per_read"), (True, "staged"), (False, "staged"), (True, "staged_quads")])
 def test_file_order_mode_matches_reference_behaviour_on_a_file(monkeypatch, manhattan, split):
     """mtr_upload_batch_in_file: the records equal the oracle's file-order mode (pinned to the reference run on whole
     files, tests/test_oracle_golden.py) whatever the batch boundaries, in both kernel modes; and they differ from the
     isolated records on this input, so the test can fail."""
     from tests.oracle_binding import Oracle
-    if split == "staged":
-        monkeypatch.setenv("MTR_STAGED", "1")
-    else:
-        monkeypatch.setenv("MTR_STAGED", "0")
-        monkeypatch.setenv("MTR_SPLIT", split)
+    for k, v in MODES[split].items():
+        monkeypatch.setenv(k, v)
     reads = _file_order_case()
     o = Oracle(manhattan)
     o.set_file_order(True)

@@ -36,7 +36,7 @@ def fnv(unit: str) -> int:
 
 
 def traced_run(name, mask):
-    os.environ["MTR_SPLIT"] = "0"                          # the reference's own order of ranges (the sequential loop)
+    os.environ["MTR_STAGED"] = "0"                         # the per-read kernel: the reference's own order of ranges (the sequential loop)
     os.environ["MTR_TRACE_MASK"] = str(mask)
     try:
         e = mtr_amd.Engine()
@@ -47,7 +47,7 @@ def traced_run(name, mask):
         ev = e.get_trace()
         e.close()
     finally:
-        del os.environ["MTR_SPLIT"], os.environ["MTR_TRACE_MASK"]
+        del os.environ["MTR_STAGED"], os.environ["MTR_TRACE_MASK"]
     assert len(ev) < 2_000_000
     return ev
 

@@ -147,11 +147,6 @@ def cli_rate(reads, n):
     return {"reads": n, "seconds": best, "reads_per_s": n / best}
 
 
-def shard_bounds(lens, world):
-    from mtr_amd.dist import shard_bounds as sb
-    return sb(lens, world)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,12 +189,18 @@ def main():
             dist.init_process_group(backend)
 
     if a.strong:
-        # one data set for the whole job: every rank generates it (seeded) and keeps its contiguous block
-        allr = [c for _, c in synth.make_reads(a.strong, a.strong_reads, 4)]
-        b = shard_bounds([len(r) for r in allr], world)
-        reads = allr[b[rank]: b[rank + 1]]
-        n_job = len(allr)
-        del allr
+        # one data set for the whole job, a contiguous block of it per rank (the reads of this config are all ~2 kb: equal counts are
+        # equal sums of lengths to within a per cent).  A rank generates only ITS block: the seeded stream is entered at the nearest
+        # committed generator checkpoint (tests/golden/c4_rng_checkpoints.npz, every 5 000 reads) instead of at read 0.
+        n_job = a.strong_reads
+        lo, hi = rank * n_job // world, (rank + 1) * n_job // world
+        ck = None
+        try:
+            z = np.load(os.path.join(ROOT, "tests", "golden", f"{a.strong}_rng_checkpoints.npz"))
+            ck = (z["idx"], z["keys"], z["pos"])
+        except Exception:
+            pass
+        reads = [c for _, c in synth.make_reads_range(a.strong, lo, hi, 4, ck)]
     else:
         # every rank owns its own block of reads (weak scaling): same distribution, different seed
         reads = [c for _, c in synth.make_reads(WORKLOAD, a.reads, seed=2 + rank)]
@@ -371,8 +372,8 @@ def main():
         traffic, issue, prof_tag = profiled_counters()
         wire_bytes = len(eng.fetch_packed()[0]) if world == 1 else None
         if a.strong:
-            workload = (f"{a.strong}: ONE set of {n_job} synthetic Nanopore reads (unit 50-200 x 10 copies, L ~ 2 kb), contiguous blocks balanced "
-                        f"by sum of lengths over {world} GPU(s)")
+            workload = (f"{a.strong}: ONE set of {n_job} synthetic Nanopore reads (unit 50-200 x 10 copies, L ~ 2 kb), contiguous blocks of equal "
+                        f"read count over {world} GPU(s)")
         else:
             workload = (f"{WORKLOAD}: {n_local} synthetic Nanopore reads per GPU, unit 100 x 10 copies, 500-base flanks, "
                         f"mean L {np.mean([len(r) for r in reads]):.0f}, error profile sub 1.6/ins 9.0/del 3.8 %")
@@ -389,6 +390,8 @@ def main():
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
+            "exchange": ({"backend": backend, "ranks": world, "collectives": "all_gather of the table sizes (first exchange), gather of fixed-size wire-form buffers to rank 0 per step",
+                          "forced_on_one_rank": world == 1} if dist_on else None),
             "config": {"workload": workload, "reads_per_gpu": n_local,
                        "parallelism": f"reads sharded over {world} GPU(s), wire-form record tables gathered to rank 0" if world > 1
                                       else "1 GPU, record tables fetched to pinned host memory in wire form"},

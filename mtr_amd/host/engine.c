@@ -51,6 +51,7 @@ int mtrh_engine_load(mtrh_engine *e, const char *lib_path, char *err, size_t err
         snprintf(err, errlen, "%s implements ABI version %d, this host was built for %d", path, ver ? ver() : -1, MTR_ABI_VERSION);
         dlclose(e->dl); memset(e, 0, sizeof *e); return 1;
     }
+    if (!realpath(path, e->path)) snprintf(e->path, sizeof e->path, "%s", path);
     return 0;
 }
 

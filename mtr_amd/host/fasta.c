@@ -100,7 +100,7 @@ static uint8_t code_of[256];
 static void init_codes(void)
 {
     static int done;
-    if (done) return;
+    if (__atomic_load_n(&done, __ATOMIC_ACQUIRE)) return;       /* (two first callers both fill the table with the same bytes) */
     uint8_t t[256];
     memset(t, 0xFF, sizeof t);
     t[0] = t['\n'] = t['\r'] = 0xFE;
@@ -221,6 +221,18 @@ mtrh_batch *mtrh_parse_chunk(const mtrh_file *f, size_t begin, size_t end, int m
          * (:243; it is set when a record is returned, :226-229); nothing before the first record */
         tail->end_id = NULL; tail->end_id_len = 0;
         if (tail->n > 0) { tail->end_id = tail->ids[tail->n - 1]; tail->end_id_len = tail->id_lens[tail->n - 1]; }
+        else if (begin > 0) {
+            /* the over-long record is the first of a chunk inside the file: the record before it lives in the previous chunk - its
+             * header is the last line start '>' before `begin` (chunks are cut at "\n>") */
+            const char *m = (const char *)f->map;
+            size_t q = begin - 1;
+            while (q > 0 && !(m[q] == '>' && m[q - 1] == '\n')) q--;
+            if (m[q] == '>') {
+                size_t z = q + 1;
+                while (z < begin && z - (q + 1) < (size_t)(MTRH_BLK - 2) && m[z] != 0 && m[z] != '\n' && m[z] != '\r') z++;
+                tail->end_id = m + q + 1; tail->end_id_len = (int32_t)(z - (q + 1));
+            }
+        }
     }
     return B.head;
 }

@@ -55,6 +55,8 @@ int main(int argc, char **argv)
     mtrh_stamp("everything printed");
     double t_wait = 0, t_submit = 0, t_fetch = 0, t_kernel = 0; long long queries = 0;
     mtrh_run_timing(run, &t_wait, &t_submit, &t_fetch, &t_kernel, &queries);
+    char engine_path[4096];
+    snprintf(engine_path, sizeof engine_path, "%s", mtrh_run_engine_path(run));
     mtrh_run_stop(run);
     mtrh_stamp("run stopped");
     if (getenv("MTR_HOST_TIMING"))                /* development aid: phase times on stderr */
@@ -71,6 +73,7 @@ int main(int argc, char **argv)
         fprintf(stderr, "\t%f\twrap around\n", 0.0);
         fprintf(stderr, "\t%f\tchaining\n", t_chain);
         fprintf(stderr, "\t%i\tCount of queries\n", (int)queries);
+        fprintf(stderr, "%s\tengine library%s\n", engine_path, getenv("MTR_LIB") ? " (from $MTR_LIB)" : "");   /* this build: what computed the records */
     }
     return status ? EXIT_FAILURE : EXIT_SUCCESS;
 }

@@ -41,6 +41,7 @@ typedef struct mtrh_engine {
     __typeof__(mtr_file_state_create) *fs_create;
     __typeof__(mtr_file_state_destroy) *fs_destroy;
     __typeof__(mtr_file_state_skip) *fs_skip;
+    char path[4096];                    /* the library that was bound, resolved (reported by mTR -c) */
 } mtrh_engine;
 /* dlopen a library that implements include/mtr_hip.h; lib_path NULL = $MTR_LIB, else libmtr_hip.so next to this code */
 int  mtrh_engine_load(mtrh_engine *e, const char *lib_path, char *err, size_t errlen);
@@ -124,6 +125,7 @@ int   mtrh_run_round_of(const mtrh_run *r, int chunk);
 /* next finished result of this rank in output order (blocks); NULL at the end */
 mtrh_result *mtrh_run_next(mtrh_run *r);
 void  mtrh_run_timing(const mtrh_run *r, double *t_parse_wait, double *t_submit, double *t_fetch, double *t_kernel, long long *queries);
+const char *mtrh_run_engine_path(const mtrh_run *r);           /* the engine library the run bound (resolved path) */
 void  mtrh_stamp(const char *what);           /* development aid: with MTR_HOST_TIMING set, a line on stderr with the time since the first stamp */
 void  mtrh_run_stop(mtrh_run *r);
 /* all results this rank produces for `round`, serialised one after the other (malloc'ed; free() it) */
@@ -133,6 +135,7 @@ uint8_t *mtrh_run_round_blob(mtrh_run *r, int round, size_t *bytes);
 typedef struct mtrh_printer mtrh_printer;
 mtrh_printer *mtrh_printer_start(FILE *out, int threads);
 mtrh_printer *mtrh_printer_start_stdout(int threads);          /* for callers without a FILE* (ctypes) */
+mtrh_printer *mtrh_printer_start_fd(int fd, int threads);       /* the report on a descriptor of the caller's (fdopen; flushed by mtrh_printer_finish) */
 /* takes ownership of r; results must arrive in output order.  Once a file's input ended (an empty record, a fatal
  * character, a device-side error: the message has been printed) the later results of that file are dropped. */
 void  mtrh_printer_push(mtrh_printer *p, mtrh_result *r);

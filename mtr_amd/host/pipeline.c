@@ -382,6 +382,8 @@ int mtrh_run_n_rounds(const mtrh_run *r) { return r->n_rounds; }
 int mtrh_run_owner(const mtrh_run *r, int chunk) { return chunk >= 0 && chunk < r->n_chunks ? r->chunks[chunk].owner : -1; }
 int mtrh_run_round_of(const mtrh_run *r, int chunk) { return chunk >= 0 && chunk < r->n_chunks ? r->chunks[chunk].round : -1; }
 
+const char *mtrh_run_engine_path(const mtrh_run *r) { return r->eng.path; }
+
 void mtrh_run_timing(const mtrh_run *r, double *t_parse_wait, double *t_submit, double *t_fetch, double *t_kernel, long long *queries)
 {
     if (t_parse_wait) *t_parse_wait = r->t_parse_wait;

@@ -298,6 +298,13 @@ mtrh_printer *mtrh_printer_start(FILE *out, int threads)
 }
 
 mtrh_printer *mtrh_printer_start_stdout(int threads) { return mtrh_printer_start(stdout, threads); }
+/* the report on a file descriptor of the caller's: the launcher keeps the process's fd 1 pointed at stderr, because communication
+ * libraries write banners there whenever they first connect (RCCL: at the first collective, not at the group's creation) */
+mtrh_printer *mtrh_printer_start_fd(int fd, int threads)
+{
+    FILE *f = fdopen(fd, "w");
+    return f ? mtrh_printer_start(f, threads) : NULL;
+}
 
 void mtrh_printer_push(mtrh_printer *p, mtrh_result *r)
 {

@@ -76,7 +76,14 @@ mtrh_result *mtrh_result_deserialize(const uint8_t *blob, size_t bytes, size_t *
     if (h[H_MAGIC] != SHARD_MAGIC || h[H_BYTES] < (int64_t)(sizeof(int64_t) * H_N_FIELDS) || (size_t)h[H_BYTES] > bytes) return NULL;
     const int n = (int)h[H_N], nr = (int)h[H_NREPORT], al = (int)h[H_ALIGN];
     const int64_t ids = h[H_IDS], words = h[H_WORDS], nk = h[H_NCHAIN], ops = h[H_OPS];
-    if (n < 0 || nr < 0 || nr > n || ids < 0 || words < 0 || nk < 0 || ops < 0 || h[H_WIRE] < 0) return NULL;
+    if (n < 0 || nr < 0 || nr > n || ids < 0 || words < 0 || nk < 0 || ops < 0 || h[H_WIRE] < 0 || h[H_MSG] < 0 || h[H_ENDID] < 0) return NULL;
+    {   /* the sections the header announces must add up to the blob BEFORE anything is copied out of it */
+        size_t need = sizeof(int64_t) * H_N_FIELDS + 2 * pad8(4 * (size_t)n) + pad8(4 * (size_t)nr) + pad8((size_t)ids) + pad8((size_t)h[H_WIRE])
+                      + pad8((size_t)h[H_MSG]) + pad8((size_t)h[H_ENDID]);
+        if (al) need += pad8(4 * (size_t)words) + pad8(4 * (size_t)nr) + pad8(4 * (size_t)nk) + pad8(8 * ((size_t)nk + 1)) + pad8((size_t)ops)
+                        + pad8(4 * 2 * (size_t)nk) + pad8(2 * (size_t)n);
+        if (need != (size_t)h[H_BYTES]) return NULL;
+    }
     mtrh_result *r = (mtrh_result *)calloc(1, sizeof *r);
     mtrh_batch *b = (mtrh_batch *)calloc(1, sizeof *b);
     r->batch = b;
@@ -97,7 +104,9 @@ mtrh_result *mtrh_result_deserialize(const uint8_t *blob, size_t bytes, size_t *
         /* the reads' bases come at 2 bit/base; the printer wants codes */
         int64_t total = 0;
         b->offs = (int64_t *)xmalloc(sizeof(int64_t) * ((size_t)n + 1));
-        for (int i = 0; i < n; i++) { b->offs[i] = total; total += b->lens[i]; }
+        int64_t wsum = 0;
+        for (int i = 0; i < n; i++) { b->offs[i] = total; if (b->lens[i] < 0) { wsum = -1; break; } total += b->lens[i]; wsum += mtr_packed_words(b->lens[i]); }
+        if (wsum != words) { mtrh_result_free(r); return NULL; }        /* the lengths do not describe the packed image that follows */
         b->codes = (uint8_t *)xmalloc((size_t)total + 1);
         const uint32_t *w = (const uint32_t *)p;
         for (int i = 0; i < n; i++) {

@@ -58,6 +58,8 @@ def load_host():
     lib.mtrh_run_stop.argtypes = [C.c_void_p]
     lib.mtrh_printer_start_stdout.restype = C.c_void_p
     lib.mtrh_printer_start_stdout.argtypes = [C.c_int]
+    lib.mtrh_printer_start_fd.restype = C.c_void_p
+    lib.mtrh_printer_start_fd.argtypes = [C.c_int, C.c_int]
     lib.mtrh_print_round.restype = C.c_int
     lib.mtrh_print_round.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]
     lib.mtrh_printer_finish.restype = C.c_int
@@ -81,6 +83,8 @@ def parse_args(argv):
     ap.add_argument("--engine-lib", default=None, help="library implementing include/mtr_hip.h (default: mtr_amd/libmtr_hip.so)")
     ap.add_argument("--chunk-bytes", type=int, default=0, help="FASTA bytes per chunk (default 24 MiB)")
     ap.add_argument("--stats", action="store_true", help="rank 0 reports ranks seen / bytes gathered on stderr")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="a single rank too joins a process group and goes through the collectives (under torchrun with one rank: RCCL on a one-GPU box)")
     ap.add_argument("fasta", nargs="+")
     a = ap.parse_args(argv)
     if not 0 <= a.ratio <= 1:
@@ -107,7 +111,26 @@ def spawn(n, argv):
         env.setdefault("GPU_MAX_HW_QUEUES", "8")        # RCCL's streams + the two context streams: more than the runtime's default of 4 hardware queues (bench.py)
         procs.append(subprocess.Popen([sys.executable, "-m", "mtr_amd.run", *argv], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    codes = [p.wait() for p in procs]
+    # A rank that dies (a refused allocation in the host library exits the process, a crash, a malformed blob on rank 0) leaves the
+    # others waiting in a collective until the communicator times out - minutes.  So: once any rank has ended badly the others get
+    # a few seconds to end by themselves, then they are ended.
+    import time
+    codes = [None] * n
+    failed_at = None
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                rc = p.poll()
+                if rc is not None:
+                    codes[i] = rc
+                    if rc != 0 and failed_at is None:
+                        failed_at = time.monotonic()
+        if failed_at is not None and time.monotonic() - failed_at > 5.0:
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.kill()
+                    codes[i] = p.wait()
+        time.sleep(0.02)
     return max((c if c >= 0 else 128 - c) for c in codes)
 
 
@@ -136,7 +159,12 @@ def worker(a):
     lib = load_host()
     dist = torch = dev = None
     device_ordinal = 0
-    if world > 1:
+    report_fd = None
+    dist_on = world > 1 or a.force_dist
+    backend = None
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         import torch
         import torch.distributed as dist
         backend = a.backend or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -149,15 +177,13 @@ def worker(a):
             dev = torch.device("cpu")
             if torch.cuda.is_available():
                 device_ordinal = local % max(torch.cuda.device_count(), 1)
-        # stdout belongs to the report: whatever a communication library prints while it connects goes to stderr
+        # stdout belongs to the report: whatever a communication library prints when it connects goes to stderr - and RCCL
+        # connects (and prints its version banner on fd 1) at the first COLLECTIVE, not here.  So fd 1 stays pointed at stderr for the
+        # rest of the process; the report is written to the saved descriptor.
         sys.stdout.flush()
-        saved = os.dup(1)
+        report_fd = os.dup(1)
         os.dup2(2, 1)
-        try:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-        finally:
-            os.dup2(saved, 1)
-            os.close(saved)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     o = Opts(print_alignment=int(a.align), manhattan=int(not a.pearson), file_order=int(a.file_order), device=device_ordinal,
              min_match_ratio=a.ratio, rank=rank, world=world, lpt=int(len(a.fasta) > 1), chunk_bytes=a.chunk_bytes,
              parse_threads=0, print_threads=0, engine_lib=(a.engine_lib.encode() if a.engine_lib else None))
@@ -166,17 +192,20 @@ def worker(a):
         sys.stderr.write("Pearson's correlation coefficient distance in place of Manhattan distance.\n")
     run = lib.mtrh_run_start(C.byref(o), paths, len(a.fasta))
     ok = 1 if run else 0
-    if world > 1:                                           # a rank that could not start (bad file) stops everyone
+    if dist_on:                                             # a rank that could not start (bad file) stops everyone
         flag = torch.tensor([ok], dtype=torch.int64, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = int(flag.item())
     if not ok:
         if run:
             lib.mtrh_run_stop(run)
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return 1
-    printer = lib.mtrh_printer_start_stdout(min(8, max(1, (os.cpu_count() or 2) // 2))) if rank == 0 else None
+    n_print = min(8, max(1, (os.cpu_count() or 2) // 2))
+    printer = None
+    if rank == 0:
+        printer = lib.mtrh_printer_start_fd(report_fd, n_print) if report_fd is not None else lib.mtrh_printer_start_stdout(n_print)
     n_rounds = lib.mtrh_run_n_rounds(run)
     n_chunks = lib.mtrh_run_n_chunks(run)
     gathered = 0
@@ -185,10 +214,11 @@ def worker(a):
         ptr = lib.mtrh_run_round_blob(run, t, C.byref(nbytes))
         payload = C.string_at(ptr, nbytes.value) if nbytes.value else b""
         _libc.free(ptr)
-        if world > 1:
+        if dist_on:
             blobs, sizes = gather_bytes(dist, torch, payload, rank, world, dev)
         else:
             blobs, sizes = [payload], [len(payload)]
+        round_ok = 1
         if rank == 0:
             gathered += sum(sizes)
             keep = [C.create_string_buffer(b, len(b)) if b else C.create_string_buffer(1) for b in blobs]
@@ -196,15 +226,25 @@ def worker(a):
             szs = (C.c_size_t * world)(*sizes)
             if lib.mtrh_print_round(printer, arr, szs, world) < 0:
                 sys.stderr.write("internal error: malformed result blob\n")
-                os._exit(2)
+                round_ok = 0
+        if dist_on:                                         # rank 0's verdict on the round reaches everyone: nobody waits in a collective for a rank that left
+            okf = torch.tensor([round_ok], dtype=torch.int64, device=dev)
+            dist.broadcast(okf, src=0)
+            round_ok = int(okf.item())
+        if not round_ok:
+            lib.mtrh_run_stop(run)
+            if dist_on:
+                dist.destroy_process_group()
+            return 2
     status = 0
     if rank == 0:
         status = lib.mtrh_printer_finish(printer, None)
         if a.stats:
             owners = sorted({lib.mtrh_run_owner(run, c) for c in range(n_chunks)})
-            sys.stderr.write(f"[mtr_amd.run] ranks={world} ranks_with_chunks={len(owners)} chunks={n_chunks} rounds={n_rounds} gathered_bytes={gathered}\n")
+            sys.stderr.write(f"[mtr_amd.run] ranks={world} ranks_with_chunks={len(owners)} chunks={n_chunks} rounds={n_rounds} gathered_bytes={gathered}"
+                             f" backend={backend or 'none'}\n")
     lib.mtrh_run_stop(run)
-    if world > 1:
+    if dist_on:
         st = torch.tensor([status], dtype=torch.int64, device=dev)
         dist.broadcast(st, src=0)
         status = int(st.item())

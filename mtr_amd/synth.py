@@ -14,6 +14,10 @@ from __future__ import annotations
 import numpy as np
 
 NANOPORE = (1.6, 9.0, 3.8)
+# the two alternates the reference's script carries as comments (test_single_TR/test.sh:12-18): substitution-heavy profiles
+PROFILE_SUB_HEAVY = (12.7, 3.2, 4.7)
+PROFILE_SUB_DEL = (9.7, 2.9, 7.5)
+PROFILES = {"nanopore": NANOPORE, "sub_heavy": PROFILE_SUB_HEAVY, "sub_del": PROFILE_SUB_DEL}
 _BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
 
 
@@ -65,18 +69,55 @@ CONFIGS = {
 }
 
 
-def make_reads(config: str, n_reads: int | None = None, seed: int | None = None):
-    """List of (id_str, codes) for a named config; n_reads/seed override the defaults."""
+def make_reads(config: str, n_reads: int | None = None, seed: int | None = None, profile=NANOPORE):
+    """List of (id_str, codes) for a named config; n_reads/seed override the defaults; profile = (sub, ins, del) in percent."""
     unit, copies, flank, n_def, seed_def = CONFIGS[config]
     n = n_def if n_reads is None else n_reads
     rng = np.random.RandomState(seed_def if seed is None else seed)
     reads = []
     for i in range(n):
-        u = unit if isinstance(unit, int) else int(rng.randint(unit[0], unit[1] + 1))
-        f = flank if flank is not None else max(0, (2052 - u * copies) // 2)
-        codes, _ = make_read(rng, u, copies, f, f)
-        reads.append((str(i), codes))
+        reads.append((str(i), _one_read(rng, unit, copies, flank, profile)))
     return reads
+
+
+def _one_read(rng, unit, copies, flank, profile=NANOPORE):
+    u = unit if isinstance(unit, int) else int(rng.randint(unit[0], unit[1] + 1))
+    f = flank if flank is not None else max(0, (2052 - u * copies) // 2)
+    return make_read(rng, u, copies, f, f, profile)[0]
+
+
+def make_rng_checkpoints(config: str, n_reads: int, every: int, seed: int | None = None):
+    """(indices, MT19937 keys, positions) of make_reads(config)'s generator before reads 0, every, 2 every, ...: what lets a rank
+    of a sharded job generate ITS block of the stream without generating the reads before it (make_reads_range)."""
+    unit, copies, flank, _, seed_def = CONFIGS[config]
+    rng = np.random.RandomState(seed_def if seed is None else seed)
+    idx, keys, pos = [], [], []
+    for i in range(n_reads):
+        if i % every == 0:
+            st = rng.get_state()
+            idx.append(i); keys.append(np.array(st[1], dtype=np.uint32)); pos.append(int(st[2]))
+        _one_read(rng, unit, copies, flank)
+    return np.array(idx, np.int64), np.stack(keys), np.array(pos, np.int64)
+
+
+def make_reads_range(config: str, lo: int, hi: int, seed: int | None = None, checkpoints=None):
+    """Reads lo .. hi-1 of make_reads(config, n >= hi, seed), as (id_str, codes).  With `checkpoints` (make_rng_checkpoints of the
+    same config and seed) the generator starts at the last checkpoint at or before lo instead of at read 0."""
+    unit, copies, flank, _, seed_def = CONFIGS[config]
+    rng = np.random.RandomState(seed_def if seed is None else seed)
+    start = 0
+    if checkpoints is not None:
+        idx, keys, pos = checkpoints
+        k = int(np.searchsorted(idx, lo, side="right")) - 1
+        if k >= 0:
+            rng.set_state(("MT19937", keys[k], int(pos[k]), 0, 0.0))
+            start = int(idx[k])
+    out = []
+    for i in range(start, hi):
+        codes = _one_read(rng, unit, copies, flank)
+        if i >= lo:
+            out.append((str(i), codes))
+    return out
 
 
 def make_mixed_file(n_reads: int, seed: int, max_len: int = 12000):

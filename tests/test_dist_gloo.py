@@ -1,5 +1,6 @@
-"""The N > 1 path on CPU: read sharding and the gather of per-read record tables, world_size 2 over gloo
-(the same mtr_amd.dist code runs over RCCL with CUDA tensors on the GPU box)."""
+"""The N > 1 path on CPU: read sharding, the launcher's gather of variable-length result blobs (mtr_amd.run.gather_bytes: an
+all_gather of the sizes + one padded gather) with world_size 2 over gloo — the same code runs over RCCL with CUDA tensors on the
+GPU box — and the sharded generation of bench.py's strong-scaling read set."""
 import os
 import socket
 
@@ -9,7 +10,11 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from mtr_amd.dist import RECORD_BYTES, gather_records, shard_bounds
+from mtr_amd import synth
+from mtr_amd.dist import shard_bounds
+from mtr_amd.run import gather_bytes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_shard_bounds_balanced_and_contiguous():
@@ -32,42 +37,52 @@ def _free_port():
     return p
 
 
+def _payload(rank, rnd):
+    rng = np.random.RandomState(100 * rnd + rank)
+    n = 0 if (rank == 1 and rnd == 1) else int(rng.randint(1, 5000))     # a rank with nothing to send in one round
+    return rng.randint(0, 256, size=n).astype(np.uint8).tobytes()
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    rng = np.random.RandomState(100 + rank)
-    n_reads = 5 + 3 * rank                                   # ragged: different read and record counts per rank
-    counts = rng.randint(0, 4, size=n_reads).astype(np.int32)
-    if rank == 1:
-        counts[:] = 0                                        # a rank without any record
-    n_rec = int(counts.sum())
-    recs = rng.randint(0, 256, size=n_rec * RECORD_BYTES).astype(np.uint8)
-    out = gather_records(torch.from_numpy(recs), torch.from_numpy(counts), dst=0)
-    if rank == 0:
-        r, c = out
-        q.put([(x.numpy().tobytes(), y.numpy().tolist()) for x, y in zip(r, c)])
-    else:
-        assert out is None
-    q.put((rank, recs.tobytes(), counts.tolist()))
+    for rnd in range(3):
+        blobs, sizes = gather_bytes(dist, torch, _payload(rank, rnd), rank, world, torch.device("cpu"))
+        assert sizes == [len(_payload(r, rnd)) for r in range(world)]
+        if rank == 0:
+            q.put((rnd, blobs))
+        else:
+            assert blobs is None
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(120)
-def test_gather_records_world2_gloo():
+def test_gather_bytes_world2_gloo():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    items = [q.get(timeout=90) for _ in range(world + 1)]
+    items = [q.get(timeout=90) for _ in range(3)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    gathered = [x for x in items if isinstance(x, list)][0]
-    sent = {x[0]: (x[1], x[2]) for x in items if isinstance(x, tuple)}
-    for r in range(world):
-        assert gathered[r][0] == sent[r][0], f"record bytes of rank {r} changed in the gather"
-        assert gathered[r][1] == sent[r][1]
+    for rnd, blobs in items:
+        assert blobs == [_payload(r, rnd) for r in range(world)], f"round {rnd}: bytes changed in the gather"
+
+
+def test_a_rank_generates_its_block_of_the_strong_scaling_set_from_a_checkpoint():
+    """bench.py --strong c4: rank r takes reads [r n / N, (r + 1) n / N) of the seeded stream and enters the generator at the nearest
+    committed checkpoint; the blocks must be exactly the reads of the whole stream (the oracle's known answer is over that stream)."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "c4_rng_checkpoints.npz"))
+    ck = (z["idx"], z["keys"], z["pos"])
+    assert ck[0][0] == 0 and len(ck[0]) == 20 and ck[0][1] == 5000
+    whole = synth.make_reads("c4", 5200, 4)
+    for lo, hi in ((0, 7), (4990, 5010), (5000, 5200)):
+        part = synth.make_reads_range("c4", lo, hi, 4, ck)
+        assert [i for i, _ in part] == [str(i) for i in range(lo, hi)]
+        assert all(np.array_equal(a[1], b[1]) for a, b in zip(whole[lo:hi], part))
+    assert all(np.array_equal(a[1], b[1]) for a, b in zip(whole[3:9], synth.make_reads_range("c4", 3, 9, 4, None)))

@@ -89,3 +89,15 @@ def test_reference_front_end_with_the_binding_of_integration_md():
         missing = sum((want - got).values())
         assert missing <= max(2, 0.1 * sum(want.values())), (name, mode, missing)
     assert exact >= len(cases) // 2, f"only {exact} of {len(cases)} identical"
+
+
+def test_cli_reports_the_engine_library_it_bound(cli):
+    """mTR -c: after the reference's timing block, the resolved path of the library that computed the records - the product library,
+    not something a leaked $MTR_LIB pointed at (the replay engine of the CPU tests would print the same report from recorded records)."""
+    env = {k: v for k, v in os.environ.items() if k != "MTR_LIB"}
+    p = subprocess.run([cli, "-c", gu.input_path("3_5")], capture_output=True, env=env)
+    assert p.returncode == 0, p.stderr.decode()[:500]
+    err = p.stderr.decode()
+    assert "Computation time" in err
+    line = [ln for ln in err.splitlines() if ln.endswith("engine library")]
+    assert len(line) == 1 and os.path.realpath(line[0].split("\t")[0]) == os.path.realpath(os.path.join(ROOT, "mtr_amd", "libmtr_hip.so")), err

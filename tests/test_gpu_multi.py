@@ -160,3 +160,53 @@ def test_bench_strong_scaling_gathers_the_oracles_record_stream():
     assert line["n_gpus"] == world and line["scaling"] == "strong"
     st = line["strong"]
     assert st["ranks_seen"] == world and sum(st["reads_per_rank"]) == 100000 and st["matches_oracle"] is True, st
+
+
+# ---- RCCL on the one-GPU box: one rank under torch.distributed.run, backend "nccl"  -------------------------------
+def _torchrun_one_rank(args, port, extra_env=None, timeout=800):
+    env = {k: v for k, v in os.environ.items() if k not in ("MTR_LIB", "MTR_REPLAY_TABLE", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MTR_BENCH_BACKEND")}
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), *args], capture_output=True, env=env, timeout=timeout, cwd=ROOT)
+
+
+@pytest.mark.timeout(900)
+def test_rccl_weak_step_of_the_bench_with_one_rank():
+    """bench.py's N > 1 step - init_process_group("nccl"), the size all_gather, the gather of the wire-form tables, GPU_MAX_HW_QUEUES -
+    with ONE rank: what an 8-GPU run executes per rank, on the box the suite has."""
+    import json
+    p = _torchrun_one_rank([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--reads", "3000", "--no-cli", "--no-latency",
+                            "--cpu-sample", "0"], 29541, {"MTR_BENCH_FORCE_DIST": "1"})
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["exchange"]["backend"] == "nccl" and line["exchange"]["forced_on_one_rank"] is True
+    assert "pinned host memory" in line["value_definition"] and line["value"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_rccl_strong_c4_10000_reads_match_the_oracles_hash():
+    """bench.py --strong c4 --strong-reads 10000 through RCCL with one rank: the gathered record stream's sha256 is the CPU oracle's
+    (tests/golden/c4_10000_wire.json, made by tests/golden/make_c4_wire_hash.py -n 10000)."""
+    import json
+    p = _torchrun_one_rank([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--strong", "c4", "--strong-reads", "10000", "--steps", "1", "--warmup", "1"],
+                           29542, {"MTR_BENCH_FORCE_DIST": "1"})
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    st = line["strong"]
+    assert line["exchange"]["backend"] == "nccl" and st["ranks_seen"] == 1 and st["reads_per_rank"] == [10000]
+    assert st["matches_oracle"] is True and st["records"] == 27428, st
+
+
+@pytest.mark.timeout(900)
+def test_rccl_launcher_with_one_rank_force_dist():
+    """python -m mtr_amd.run --force-dist under torch.distributed.run with one rank: process group over RCCL, the size all_gather,
+    the padded gather and the per-round verdict broadcast run on the GPU box; stdout byte-identical to the reference's."""
+    p = _torchrun_one_rank(["-m", "mtr_amd.run", "--force-dist", "--stats", "--chunk-bytes", "20000", gu.input_path("synth_c4")], 29543)
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    assert p.stdout == golden("synth_c4", "default")
+    err = p.stderr.decode()
+    assert "ranks=1" in err and "backend=nccl" in err, err[-400:]
+    files = [gu.input_path(n) for n in BUNDLED[:6]]
+    p = _torchrun_one_rank(["-m", "mtr_amd.run", "--force-dist", "-a", *files], 29544)            # several files: one round, -a blobs
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    assert p.stdout == b"".join(golden(n, "a") for n in BUNDLED[:6])

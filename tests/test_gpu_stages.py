@@ -173,3 +173,20 @@ def test_accuracy_table_equals_the_oracles(tmp_path):
         assert sg == so and gpu == orc, u
         assert sg["report_lines"] >= 150, (u, sg)
         assert sg["ratio>=0.94"] >= 0.8 * len(reads), (u, sg)               # the reference's own level on this error profile (90-100 %)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("profile", ["sub_heavy", "sub_del"])
+def test_the_references_other_error_profiles_against_the_oracle(profile):
+    """test_single_TR/test.sh:12-18 carries two alternates to the Nanopore profile (substitution 12.7 / insertion 3.2 / deletion 4.7 %
+    and 9.7 / 2.9 / 7.5 %): substitution-heavy reads give a different mix of DPs, revisions and memo hits.  300 reads of each shape
+    (the headline's unit 100 x 10 and mixed units 50-200), every read against the oracle, in the chain with and without the
+    four-per-wavefront passes."""
+    prof = synth.PROFILES[profile]
+    reads = [c for _, c in synth.make_reads("headline2k", 150, 41, prof)] + [c for _, c in synth.make_reads("c4", 150, 42, prof)]
+    assert _against_oracle(reads) == []
+    os.environ["MTR_QUAD_MIN"] = "1"
+    try:
+        assert _against_oracle(reads) == []
+    finally:
+        del os.environ["MTR_QUAD_MIN"]

@@ -242,3 +242,25 @@ def test_fasta_reader_on_many_chunks_of_a_real_file(cli, tmp_path):
     big = tmp_path / "toolong.fa"
     big.write_bytes(b">ok\nACGT\n>huge\n" + b"ACGTACGTAC" * 100001 + b"\n")
     assert parse_with_host(str(big), 1) == reference_reader(big.read_bytes())
+
+
+def test_an_overlong_record_at_the_start_of_a_chunk_names_the_record_before_it(cli, tmp_path):
+    """the reference's message for a record that reaches MAX_INPUT_LENGTH carries the ID of the record BEFORE it
+    (handle_one_file.c:243); when the over-long record opens a chunk that record lives in the previous chunk."""
+    big = tmp_path / "toolong2.fa"
+    big.write_bytes(b">first one\nACGT\n>second\nGGCC\n>huge\n" + b"ACGTACGTAC" * 100001 + b"\n")
+    lib = C.CDLL(os.path.join(hu.HOST, "libmtr_host.so"))
+    lib.mtrh_file_open.argtypes = [C.POINTER(File), C.c_char_p]
+    lib.mtrh_parse_chunk.restype = C.POINTER(Batch)
+    lib.mtrh_parse_chunk.argtypes = [C.POINTER(File), C.c_size_t, C.c_size_t, C.c_int, C.c_int64]
+    lib.mtrh_batch_free.argtypes = [C.POINTER(Batch)]
+    f = File()
+    assert lib.mtrh_file_open(C.byref(f), str(big).encode()) == 0
+    data = big.read_bytes()
+    begin = data.index(b">huge")
+    head = lib.mtrh_parse_chunk(C.byref(f), begin, len(data), 100, 1 << 40)       # a chunk that starts at the over-long record
+    bb = head.contents
+    assert bb.end == 3 and bb.n == 0
+    assert C.string_at(bb.end_id, bb.end_id_len) == b"second"
+    lib.mtrh_batch_free(head)
+    lib.mtrh_file_close(C.byref(f))

@@ -102,8 +102,9 @@ FILE_ORDER = os.path.join(GOLDEN, "file_order")
 @pytest.mark.parametrize("mode", ["default", "p"])
 def test_oracle_file_order_mode_matches_reference_run_on_whole_file(oracle_cli, name, mode):
     """-B = the reference's own behaviour on a multi-read file: every capture point identical.  The printed chains may
-    differ where two chains tie (the reference orders its set by heap address, chaining.cpp:201), so of stdout only a
-    large overlap of the two multisets of lines is asked."""
+    differ where two chains tie (the reference orders its set by heap address, chaining.cpp:201; the oracle by insertion): stdout
+    (of the stock binary) may differ only in the CHOICE of the chain: on at most a quarter of the reads, and there every printed
+    line of either side must be one of the read's recorded alignments (capture point G4)."""
     fa = os.path.join(FILE_ORDER, name + ".fa")
     with tempfile.NamedTemporaryFile(suffix=".jsonl") as cap:
         p = subprocess.run([oracle_cli, "-B", *FLAGS[mode], "-l", "1", "-C", cap.name, fa], capture_output=True, check=True)
@@ -113,9 +114,35 @@ def test_oracle_file_order_mode_matches_reference_run_on_whole_file(oracle_cli, 
         assert x == y, f"capture line {i} differs for {name} [{mode}]:\n got  {x[:200]!r}\n want {y[:200]!r}"
     assert len(got) == len(want)
     import collections
-    ref_out = collections.Counter(open(os.path.join(FILE_ORDER, f"{name}.{mode}.stdout"), "rb").read().split(b"\n"))
-    our_out = collections.Counter(p.stdout.split(b"\n"))
-    assert sum((ref_out & our_out).values()) >= 0.9 * sum(ref_out.values())
+    import json
+    import struct
+
+    def by_read(text):
+        d = collections.OrderedDict()
+        for ln in text.split(b"\n"):
+            if ln:
+                d.setdefault(ln.split(b"\t")[0], []).append(ln)
+        return d
+
+    def line_of(g):        # chaining.cpp:127-143: the ratio column is (float) matches / repeat_len printed with %f
+        ratio = struct.unpack("f", struct.pack("f", g["mat"] / g["repeat_len"]))[0] if g["repeat_len"] else 0.0
+        return ("%s\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%f\t%d\t%d\t%d\t%s" % (g["id"], g["L"], g["rep_start"] + 1, g["rep_end"] + 1, g["repeat_len"], g["period"],
+                g["copies"], g["mat"], ratio, g["mis"], g["ins"], g["del"], g["unit"])).encode()
+
+    ref_out = by_read(open(os.path.join(FILE_ORDER, f"{name}.{mode}.stdout"), "rb").read())
+    our_out = by_read(p.stdout)
+    cands = collections.defaultdict(set)
+    for ln in want:
+        if b'"t":"G4"' in ln:
+            g = json.loads(ln)
+            cands[g["id"].encode()].add(line_of(g))
+    differing = [rid for rid in set(ref_out) | set(our_out) if ref_out.get(rid) != our_out.get(rid)]
+    assert len(differing) <= len(ref_out) // 4, differing
+    for rid in differing:
+        for ln in ref_out.get(rid, []) + our_out.get(rid, []):
+            assert ln in cands[rid], f"{name} [{mode}] read {rid!r}: a printed line is none of the read's recorded alignments: {ln[:120]!r}"
+        # (the two chains need not even tie: the sweep's erase-skips-the-successor quirk, chaining.cpp:316-328, makes the kept
+        # chain depend on the set's iteration order, which is the heap's - m21 of mixed_lengths -p: 1800 against 1809 matches)
 
 
 @pytest.mark.parametrize("mode", ["default", "p", "a"])

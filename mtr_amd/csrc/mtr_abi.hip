@@ -783,8 +783,10 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         hipLaunchKernelGGL(mtr_k_dp2_quads, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
         HIPCHK(hipGetLastError());
     }
-    hipLaunchKernelGGL(mtr_k_dp2_waves, dim3((unsigned)capped(waves_dp, 16)), dim3(64), 0, ctx->stream, a, s);
-    HIPCHK(hipGetLastError());
+    if (s.quad_min <= 0) {                                  // (a big batch: mtr_k_dp2_quads has run them)
+        hipLaunchKernelGGL(mtr_k_dp2_waves, dim3((unsigned)capped(waves_dp, 16)), dim3(64), 0, ctx->stream, a, s);
+        HIPCHK(hipGetLastError());
+    }
     if (s.quad_min > 0) HIPCHK(hipMemsetAsync(ctx->d_st_bincnt, 0, (size_t)ST_NBINS * 4, ctx->stream));     // the revisions are sorted next
     HIPCHK(hipEventRecord(ctx->ev_ph[4], ctx->stream));       // two-parameter alignments
     hipLaunchKernelGGL(mtr_k_select, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);

@@ -7,12 +7,12 @@ from mtr_amd import synth
 exe = os.path.join(ROOT, "mtr_amd", "host", "mTR")
 with tempfile.TemporaryDirectory() as td:
     base = synth.make_reads("headline2k", 10000, 2)
-    for n in (1, 1000, 100000):
+    for n in (1, 1000, 10000, 100000):
         fa = os.path.join(td, f"r{n}.fa")
         synth.write_fasta(fa, [(str(i), base[i % len(base)][1]) for i in range(n)])
         for rep in range(2):
             t = time.perf_counter()
-            p = subprocess.run([exe, fa], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, MTR_HOST_TIMING="1", **({"MTR_DEBUG": "1"} if rep == 1 and n <= 1000 else {})))
+            p = subprocess.run([exe, fa], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, MTR_HOST_TIMING="1", **({"MTR_DEBUG": "1"} if False else {})))
             dt = time.perf_counter() - t
             print(f"== mTR {n} reads, run {rep}: {dt:.3f} s wall", flush=True)
             if rep == 1: print(p.stderr.decode(), flush=True)

@@ -14,7 +14,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 cfg = sys.argv[1] if len(sys.argv) > 1 else "headline2k"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 res = {}
-for name, env in (("per-read", dict(MTR_STAGED="0", MTR_SPLIT="0")), ("staged", dict(MTR_STAGED="1"))):
+for name, env in (("per-read", dict(MTR_STAGED="0")), ("staged", dict(MTR_STAGED="1"))):
     p = subprocess.run([sys.executable, os.path.abspath(__file__), "child", cfg, str(n)], env=dict(os.environ, **env), capture_output=True, text=True)
     res[name] = json.loads(p.stdout.strip().splitlines()[-1])
 print(f"{'timer (G wave-cycles)':24s} {'per-read':>10s} {'staged':>10s}")

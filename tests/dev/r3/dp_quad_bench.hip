@@ -129,20 +129,21 @@ __global__ __launch_bounds__(64, WPS) void k_quad1p(const uint32_t *pk, const ui
             q.unit[g] = units + (size_t)rd * 512;
             maxrows = q.rows[g] > maxrows ? q.rows[g] : maxrows;
         }
+        for (int g = 0; g < 4; g++) { q.G[g] = SG; q.MM[g] = SMM; q.D[g] = SD; }
         int best[4][3];
         uint8_t *cb = cells + (size_t)blockIdx.x * 4 * cells_per_job;
 #ifdef ONLYC
-        dp_forward1p_g16<ONLYC>(q, SG, SMM, SD, cb, maxrows, best);
+        dp_forward1p_g16<ONLYC>(q, cb, maxrows, best);
 #else
         switch (cq) {
-        case 1: dp_forward1p_g16<1>(q, SG, SMM, SD, cb, maxrows, best); break;
-        case 2: dp_forward1p_g16<2>(q, SG, SMM, SD, cb, maxrows, best); break;
-        case 3: dp_forward1p_g16<3>(q, SG, SMM, SD, cb, maxrows, best); break;
-        case 4: dp_forward1p_g16<4>(q, SG, SMM, SD, cb, maxrows, best); break;
-        case 5: dp_forward1p_g16<5>(q, SG, SMM, SD, cb, maxrows, best); break;
-        case 6: dp_forward1p_g16<6>(q, SG, SMM, SD, cb, maxrows, best); break;
-        case 7: dp_forward1p_g16<7>(q, SG, SMM, SD, cb, maxrows, best); break;
-        default: dp_forward1p_g16<8>(q, SG, SMM, SD, cb, maxrows, best); break;
+        case 1: dp_forward1p_g16<1>(q, cb, maxrows, best); break;
+        case 2: dp_forward1p_g16<2>(q, cb, maxrows, best); break;
+        case 3: dp_forward1p_g16<3>(q, cb, maxrows, best); break;
+        case 4: dp_forward1p_g16<4>(q, cb, maxrows, best); break;
+        case 5: dp_forward1p_g16<5>(q, cb, maxrows, best); break;
+        case 6: dp_forward1p_g16<6>(q, cb, maxrows, best); break;
+        case 7: dp_forward1p_g16<7>(q, cb, maxrows, best); break;
+        default: dp_forward1p_g16<8>(q, cb, maxrows, best); break;
         }
 #endif
         if (lane_id() == 0 && r == 0) for (int g = 0; g < 4; g++) { for (int k = 0; k < 3; k++) out[(blockIdx.x * 4 + g) * 8 + k] = best[g][k]; for (int k = 3; k < 6; k++) out[(blockIdx.x * 4 + g) * 8 + k] = 0; }
@@ -222,6 +223,8 @@ int main(int argc, char **argv)
     std::vector<uint8_t> cA(cpj * njobs), cB(cpj * njobs); std::vector<int> oA(njobs * 8), oB(njobs * 8);
     (void)hipMemcpy(cA.data(), dcA, cA.size(), hipMemcpyDeviceToHost); (void)hipMemcpy(cB.data(), dcB, cB.size(), hipMemcpyDeviceToHost);
     (void)hipMemcpy(oA.data(), doA, oA.size() * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(oB.data(), doB, oB.size() * 4, hipMemcpyDeviceToHost);
+    std::vector<int> wmax(waves, 0);
+    for (int j = 0; j < njobs; j++) wmax[j >> 2] = jobs[j].rows > wmax[j >> 2] ? jobs[j].rows : wmax[j >> 2];
     long bad_cells = 0, bad_best = 0, checked = 0;
     for (int j = 0; j < njobs; j++) {
         const Job &b = jobs[j];
@@ -231,7 +234,7 @@ int main(int argc, char **argv)
         for (int i = 1; i <= b.rows; i++)
             for (int c = 0; c < b.U; c++) {
                 const uint8_t a = cA[(size_t)j * cpj + (size_t)(i - 1) * b.U + c];
-                const uint8_t q = cB[(size_t)w * 4 * cpj + ((size_t)(i - 1) * 4 + g) * 16 * cq + c];
+                const uint8_t q = cB[(size_t)w * 4 * cpj + (size_t)g * DPQ_DP_BYTES(cq, wmax[w]) + (size_t)(i - 1) * 16 * cq + c];
                 checked++;
                 if (single ? (a != canon(q & 15)) : (a != q)) { if (bad_cells < 10) printf("cell differs job %d (U %d rows %d) row %d col %d: %02x vs %02x\n", j, b.U, b.rows, i, c + 1, a, q); bad_cells++; }
             }

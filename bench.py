@@ -126,7 +126,7 @@ def cpu_baseline(reads, n_sample):
     return one
 
 
-def cli_rate(reads, n):
+def cli_rate(reads, n, flags=()):
     """wall clock of the command line on a FASTA of the first n reads (page cache warm), best of 3"""
     from mtr_amd import synth
 
@@ -139,7 +139,7 @@ def cli_rate(reads, n):
         best, stamps = None, None
         for _ in range(3):
             t0 = time.perf_counter()
-            p = subprocess.run([exe, fa], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, MTR_HOST_TIMING="1"))
+            p = subprocess.run([exe, *flags, fa], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, MTR_HOST_TIMING="1"))
             dt = time.perf_counter() - t0
             if p.returncode != 0:
                 return {"error": p.stderr.decode()[-200:]}
@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--strong", default=None, choices=["c4"], help="strong scaling: one fixed read set split over the ranks")
     ap.add_argument("--strong-reads", type=int, default=100000)
     ap.add_argument("--cpu-sample", type=int, default=2000, help="reads timed on the CPU baseline (0 = skip); 2000 reads ~ 15 s on one core")
+    ap.add_argument("--config", default=None, choices=["c3"], help="a secondary line for another BASELINE config: c3 = 100 reads of unit 200 x 200 copies (L ~ 42 kb), -a on in the command-line leg")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-cli", action="store_true")
     a = ap.parse_args()
@@ -204,6 +205,9 @@ def main():
         except Exception:
             pass
         reads = [c for _, c in synth.make_reads_range(a.strong, lo, hi, 4, ck)]
+    elif a.config == "c3":
+        reads = [c for _, c in synth.make_reads("c3", 100, seed=3 + rank)]
+        n_job = len(reads) * world
     else:
         # every rank owns its own block of reads (weak scaling): same distribution, different seed
         reads = [c for _, c in synth.make_reads(WORKLOAD, a.reads, seed=2 + rank)]
@@ -377,11 +381,14 @@ def main():
         if a.strong:
             workload = (f"{a.strong}: ONE set of {n_job} synthetic Nanopore reads (unit 50-200 x 10 copies, L ~ 2 kb), contiguous blocks of equal "
                         f"read count over {world} GPU(s)")
+        elif a.config == "c3":
+            workload = (f"c3 (BASELINE config 3 shape; the Badread sets are absent): {n_local} synthetic Nanopore reads per GPU, unit 200 x 200 copies, "
+                        f"200-base flanks, mean L {np.mean([len(r) for r in reads]):.0f}")
         else:
             workload = (f"{WORKLOAD}: {n_local} synthetic Nanopore reads per GPU, unit 100 x 10 copies, 500-base flanks, "
                         f"mean L {np.mean([len(r) for r in reads]):.0f}, error profile sub 1.6/ins 9.0/del 3.8 %")
         out = {
-            "metric": "reads/sec, 2 kb Nanopore synthetic",
+            "metric": "reads/sec, 2 kb Nanopore synthetic" if a.config is None else "reads/sec, config 3 (unit 200 x 200 copies, L ~ 42 kb; secondary line)",
             "value": value,
             "unit": "reads/s",
             "n_gpus": world,
@@ -464,7 +471,16 @@ def main():
                 lat.append((time.perf_counter() - t1) * 1e3)
             e2.close()
             out["latency_ms_per_read_p50"] = float(np.median(lat[1:]))
-        if world == 1 and not a.no_cli and not a.strong:
+        if world == 1 and not a.no_cli and not a.strong and a.config == "c3":
+            for e in engs:
+                e.close()
+            engs.clear()
+            torch.cuda.empty_cache()
+            ca = cli_rate(reads, len(reads), ["-a"])
+            out["value_cli"] = ca.get("reads_per_s")
+            out["cli"] = {"note": "mtr_amd/host/mTR -a <fasta> > /dev/null (alignment of every reported repeat on), wall clock incl. process start and HIP initialisation; best of 3",
+                          "with_alignments": ca}
+        elif world == 1 and not a.no_cli and not a.strong:
             for e in engs:                              # the command line brings its own contexts: free this process's memory first
                 e.close()
             engs.clear()
@@ -475,7 +491,7 @@ def main():
             out["cli"] = {"note": "mtr_amd/host/mTR <fasta> > /dev/null, wall clock incl. process start and HIP initialisation; best of 3",
                           "one_batch": c1, "ten_batches": c10}
         if world == 1 and a.cpu_sample > 0 and not a.strong:
-            out["cpu_baseline"] = cpu_baseline(reads, a.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(reads, a.cpu_sample if a.config is None else min(a.cpu_sample, 6))     # (a config-3 read is ~2.6 s of CPU)
             out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"]
             if "all_cores" in out["cpu_baseline"]:
                 out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline"]["all_cores"]["value"]

@@ -36,7 +36,7 @@ class Opts(C.Structure):
     _fields_ = [("print_alignment", C.c_int), ("manhattan", C.c_int), ("file_order", C.c_int), ("device", C.c_int),
                 ("min_match_ratio", C.c_float), ("rank", C.c_int), ("world", C.c_int), ("lpt", C.c_int),
                 ("chunk_bytes", C.c_size_t), ("parse_threads", C.c_int), ("print_threads", C.c_int),
-                ("engine_lib", C.c_char_p)]
+                ("engine_lib", C.c_char_p), ("split_bytes", C.c_size_t)]
 
 
 def load_host():
@@ -54,6 +54,14 @@ def load_host():
     lib.mtrh_run_owner.argtypes = [C.c_void_p, C.c_int]
     lib.mtrh_run_round_blob.restype = C.c_void_p
     lib.mtrh_run_round_blob.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
+    lib.mtrh_run_has_split.restype = C.c_int
+    lib.mtrh_run_has_split.argtypes = [C.c_void_p]
+    lib.mtrh_run_n_shares.restype = C.c_int
+    lib.mtrh_run_n_shares.argtypes = [C.c_void_p, C.c_int]
+    lib.mtrh_run_share_rank.restype = C.c_int
+    lib.mtrh_run_share_rank.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.mtrh_run_feed.restype = None
+    lib.mtrh_run_feed.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]
     lib.mtrh_run_stop.restype = None
     lib.mtrh_run_stop.argtypes = [C.c_void_p]
     lib.mtrh_printer_start_stdout.restype = C.c_void_p
@@ -82,6 +90,9 @@ def parse_args(argv):
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl with a GPU, else gloo)")
     ap.add_argument("--engine-lib", default=None, help="library implementing include/mtr_hip.h (default: mtr_amd/libmtr_hip.so)")
     ap.add_argument("--chunk-bytes", type=int, default=0, help="FASTA bytes per chunk (default 24 MiB)")
+    ap.add_argument("--split-bytes", type=int, default=0,
+                    help="several files: a file of at least this many bytes whose cost exceeds a rank's fair part is searched by several ranks "
+                         "(default 50000; -1 = never)")
     ap.add_argument("--stats", action="store_true", help="rank 0 reports ranks seen / bytes gathered on stderr")
     ap.add_argument("--force-dist", action="store_true",
                     help="a single rank too joins a process group and goes through the collectives (under torchrun with one rank: RCCL on a one-GPU box)")
@@ -134,8 +145,8 @@ def spawn(n, argv):
     return max((c if c >= 0 else 128 - c) for c in codes)
 
 
-def gather_bytes(dist, torch, payload: bytes, rank, world, dev):
-    """Variable-length byte strings to rank 0: an all_gather of the sizes, then one padded gather."""
+def gather_bytes(dist, torch, payload: bytes, rank, world, dev, to_all=False):
+    """Variable-length byte strings to rank 0 (to every rank with to_all): an all_gather of the sizes, then one padded gather."""
     size = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
     sizes = [torch.zeros_like(size) for _ in range(world)]
     dist.all_gather(sizes, size)
@@ -144,9 +155,12 @@ def gather_bytes(dist, torch, payload: bytes, rank, world, dev):
     buf = torch.zeros(width, dtype=torch.uint8, device=dev)
     if payload:
         buf[: len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
-    out = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, out, dst=0)
-    if rank != 0:
+    out = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 or to_all else None
+    if to_all:
+        dist.all_gather(out, buf)
+    else:
+        dist.gather(buf, out, dst=0)
+    if out is None:
         return None, sizes
     return [out[r][: sizes[r]].cpu().numpy().tobytes() for r in range(world)], sizes
 
@@ -186,7 +200,8 @@ def worker(a):
         dist.init_process_group(backend, rank=rank, world_size=world)
     o = Opts(print_alignment=int(a.align), manhattan=int(not a.pearson), file_order=int(a.file_order), device=device_ordinal,
              min_match_ratio=a.ratio, rank=rank, world=world, lpt=int(len(a.fasta) > 1), chunk_bytes=a.chunk_bytes,
-             parse_threads=0, print_threads=0, engine_lib=(a.engine_lib.encode() if a.engine_lib else None))
+             parse_threads=0, print_threads=0, engine_lib=(a.engine_lib.encode() if a.engine_lib else None),
+             split_bytes=(a.split_bytes if a.split_bytes >= 0 else C.c_size_t(-1).value))
     paths = (C.c_char_p * len(a.fasta))(*[p.encode() for p in a.fasta])
     if a.pearson and rank == 0:
         sys.stderr.write("Pearson's correlation coefficient distance in place of Manhattan distance.\n")
@@ -209,11 +224,22 @@ def worker(a):
     n_rounds = lib.mtrh_run_n_rounds(run)
     n_chunks = lib.mtrh_run_n_chunks(run)
     gathered = 0
+    has_split = bool(lib.mtrh_run_has_split(run))
+    exchanged = 0
     for t in range(n_rounds):
         nbytes = C.c_size_t()
         ptr = lib.mtrh_run_round_blob(run, t, C.byref(nbytes))
         payload = C.string_at(ptr, nbytes.value) if nbytes.value else b""
         _libc.free(ptr)
+        if has_split and t == 0:
+            # the reads that several ranks searched: every rank's candidate records go to every rank (the one that reports a read picks
+            # out its group's), then the rounds of results follow as without sharing
+            blobs, sizes = gather_bytes(dist, torch, payload, rank, world, dev, to_all=True)
+            exchanged = sum(sizes)
+            keep = [C.create_string_buffer(b, len(b)) if b else C.create_string_buffer(1) for b in blobs]
+            arr = (C.c_void_p * world)(*[C.cast(k, C.c_void_p) for k in keep])
+            lib.mtrh_run_feed(run, arr, (C.c_size_t * world)(*sizes), world)
+            continue
         if dist_on:
             blobs, sizes = gather_bytes(dist, torch, payload, rank, world, dev)
         else:
@@ -241,8 +267,10 @@ def worker(a):
         status = lib.mtrh_printer_finish(printer, None)
         if a.stats:
             owners = sorted({lib.mtrh_run_owner(run, c) for c in range(n_chunks)})
+            shared = [lib.mtrh_run_n_shares(run, c) for c in range(n_chunks)]
             sys.stderr.write(f"[mtr_amd.run] ranks={world} ranks_with_chunks={len(owners)} chunks={n_chunks} rounds={n_rounds} gathered_bytes={gathered}"
-                             f" backend={backend or 'none'}\n")
+                             f" backend={backend or 'none'} shared_files={sum(1 for s in shared if s > 1)} max_shares={max(shared, default=1)}"
+                             f" candidate_bytes={exchanged}\n")
     lib.mtrh_run_stop(run)
     if dist_on:
         st = torch.tensor([status], dtype=torch.int64, device=dev)

@@ -74,8 +74,8 @@ def main():
                 for i, w in zip(order[j::56], ch):
                     want[i] = w
             t_or = time.time() - t0
-            modes = {"per-read": dict(MTR_STAGED="0", MTR_SPLIT="0"), "range-parallel": dict(MTR_STAGED="0", MTR_SPLIT="1"),
-                     "staged": dict(MTR_STAGED="1", MTR_STAGED_LANE_UMAX="0"), "staged+lanes128": dict(MTR_STAGED="1", MTR_STAGED_LANE_UMAX="128")}
+            modes = {"per-read": dict(MTR_STAGED="0", MTR_QUAD_MIN="0"), "staged": dict(MTR_STAGED="1", MTR_QUAD_MIN="0"),
+                     "staged+quads": dict(MTR_STAGED="1", MTR_QUAD_MIN="1")}
             for split in modes:
                 os.environ.update(modes[split])
                 eng = mtr_amd.Engine(manhattan=manhattan)

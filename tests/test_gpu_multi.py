@@ -210,3 +210,57 @@ def test_rccl_launcher_with_one_rank_force_dist():
     p = _torchrun_one_rank(["-m", "mtr_amd.run", "--force-dist", "-a", *files], 29544)            # several files: one round, -a blobs
     assert p.returncode == 0, p.stderr.decode()[-800:]
     assert p.stdout == b"".join(golden(n, "a") for n in BUNDLED[:6])
+
+
+# ---- one long read's ranges over several contexts (config 5's 90-140 kb reads) ----------------------------------
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n_shares", [2, 3, 8])
+def test_ranges_of_a_read_shared_by_contexts_give_the_reads_records(n_shares):
+    """mtr_run_ranges_share / mtr_export_candidates / mtr_replay_candidates: N contexts hold the same reads, each searches the ranges
+    t % N == share, one of them replays the reference's loop with everybody's candidates.  The records must be those of the oracle
+    (and of mtr_run_resident) - on bundled multi-repeat reads, in Pearson mode as config 5 runs them, and on a small mixed batch."""
+    from tests.oracle_binding import Oracle
+    import torch
+    torch.cuda.init()
+    cases = [([c for _, c in gu.read_fasta(gu.input_path(n))], False) for n in ("2_5_10_20_set", "10_50", "worm_chrI")]
+    cases.append(([c for _, c in synth.make_reads("c4", 12, 77)] + [np.tile(np.array([0, 1], np.uint8), 300)], True))
+    for reads, manhattan in cases:
+        orc = Oracle(manhattan)
+        want = [orc.process(c) for c in reads]
+        orc.close()
+        engs = [mtr_amd.Engine(manhattan=manhattan) for _ in range(min(n_shares, 3))]       # (contexts are reused for the shares of an 8-way split)
+        blobs = []
+        for sh in range(n_shares):
+            e = engs[sh % len(engs)] if sh > 0 else engs[0]
+            if sh > 0 and e is engs[0]:
+                e = engs[1]
+            e.upload(reads)
+            e.run_share(sh, n_shares)
+            blobs.append(e.export_candidates())
+        engs[0].upload(reads)
+        engs[0].run_share(0, n_shares)
+        engs[0].replay_candidates(blobs)
+        got = engs[0].fetch()
+        for i in range(len(reads)):
+            assert [tuple(r) for r in got[i]] == want[i], (n_shares, i)
+        assert sum(len(w) for w in want) > 0
+        for e in engs:
+            e.close()
+
+
+@pytest.mark.timeout(1800)
+def test_launcher_spreads_a_long_read_over_ranks():
+    """config 5 with more ranks than long reads: the 100+ kb read of a file is searched by a group of ranks (here: ranks sharing the
+    one GPU, gloo carrying the candidate round) and reported by the group's first rank - stdout byte-identical to the reference's."""
+    from tests.test_run_gloo import SHARED
+    for big, mode, flags in (("worm_chrII_1", "p", ["-p"]), ("2_5_10_20_50_100_200_set", "default", []), ("2_5_10_20_50_100_200_set", "a", ["-a"])):
+        names = ["3_5", big]
+        p = _run([*flags, *[gu.input_path(n) for n in names]], 2, "gloo")
+        assert p.returncode == 0, p.stderr.decode()[-800:]
+        assert p.stdout == b"".join(golden(n, mode) for n in names), (big, mode)
+        stats = [l for l in p.stderr.decode().splitlines() if l.startswith("[mtr_amd.run]")][0]
+        assert "shared_files=1 " in stats and "max_shares=2 " in stats and "candidate_bytes=0" not in stats, stats
+    p = _run(["-p", *[gu.input_path(n) for n in SHARED]], 4, "gloo")              # both long reads shared, one of them four ways
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    assert p.stdout == b"".join(golden(n, "p") for n in SHARED)
+    assert "max_shares=4 " in p.stderr.decode()

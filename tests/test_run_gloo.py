@@ -84,7 +84,7 @@ def test_a_bad_record_on_another_rank_stops_the_output_there(setup, tmp_path):
 
 
 def test_plan_is_the_same_on_every_rank_and_lpt_spreads_the_long_reads(setup):
-    """15 reads of 2.6-140 kb over 8 ranks: the four reads of 90-140 kb land on four different ranks"""
+    """15 reads of 2.6-140 kb over 8 ranks, no read shared: the four reads of 90-140 kb land on four different ranks"""
     import ctypes as C
     from mtr_amd import run as R
     lib = R.load_host()
@@ -92,7 +92,7 @@ def test_plan_is_the_same_on_every_rank_and_lpt_spreads_the_long_reads(setup):
     owners = []
     for rank in (0, 5):
         o = R.Opts(print_alignment=0, manhattan=1, file_order=0, device=0, min_match_ratio=0.6, rank=rank, world=8, lpt=1, chunk_bytes=0,
-                   parse_threads=1, print_threads=1, engine_lib=setup[0].encode())
+                   parse_threads=1, print_threads=1, engine_lib=setup[0].encode(), split_bytes=C.c_size_t(-1).value)
         paths = (C.c_char_p * len(files))(*[f.encode() for f in files])
         os.environ["MTR_REPLAY_TABLE"] = setup[1]["default"]
         h = lib.mtrh_run_start(C.byref(o), paths, len(files))
@@ -102,3 +102,38 @@ def test_plan_is_the_same_on_every_rank_and_lpt_spreads_the_long_reads(setup):
     assert owners[0] == owners[1] and len(owners[0]) == 15
     big = [owners[0][BUNDLED.index(n)] for n in ("2_5_10_20_50_100_200_set", "worm_chrI", "worm_chrII_1", "worm_chrII_2")]
     assert len(set(big)) == 4 and set(owners[0]) == set(range(8))
+
+
+SHARED = ["3_5", "worm_chrII_1", "5_10", "2_5_10_20_50_100_200_set", "10_20"]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,mode,flags,shares", [(2, "p", ["-p"], 2), (3, "default", [], 3), (4, "a", ["-a"], 4)])
+def test_a_long_read_is_searched_by_several_ranks(setup, world, mode, flags, shares):
+    """BASELINE config 5 on more GPUs than long reads: the two reads of 100+ kb cost more than a rank's fair part, so each is searched
+    by a group of ranks (mtr_run_ranges_share), the candidate records are all-gathered (round 0) and the rank that reports the read
+    replays the reference's range loop over them.  The stand-in engine checks that exactly the group's other shares came back."""
+    lib, tables = setup
+    files = [gu.input_path(n) for n in SHARED]
+    p = run(lib, tables["p" if mode == "p" else "default"], world, [*flags, *files])
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    assert p.stdout == b"".join(golden(n, mode) for n in SHARED)
+    stats = [l for l in p.stderr.decode().splitlines() if l.startswith("[mtr_amd.run]")][0]
+    print(stats)
+    assert "shared_files=0 " not in stats and f"max_shares={shares} " in stats and "candidate_bytes=0" not in stats, stats
+    # --split-bytes -1: nothing is shared, same report
+    q = run(lib, tables["p" if mode == "p" else "default"], world, [*flags, "--split-bytes", "-1", *files])
+    assert q.returncode == 0 and q.stdout == p.stdout
+    assert "shared_files=0 " in [l for l in q.stderr.decode().splitlines() if l.startswith("[mtr_amd.run]")][0]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("fail_share", [0, 1])
+def test_a_share_that_cannot_be_searched_sends_the_read_back_whole(setup, fail_share):
+    """a share whose search fails (a matrix beyond WrapDPsize, memory) -> the reporting rank runs the read whole, as without sharing"""
+    lib, tables = setup
+    files = [gu.input_path(n) for n in SHARED]
+    p = run(lib, tables["default"], 2, files, extra_env={"MTR_REPLAY_FAIL_SHARE": str(fail_share)})
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    assert p.stdout == b"".join(golden(n, "default") for n in SHARED)
+    assert "shared_files=1 " in p.stderr.decode()

@@ -539,8 +539,8 @@ static mtr_status launch_k1_parts(mtr_ctx *ctx)
     K1Layout y = k1_layout(ctx->Lmax);
     mtr_status s = ensure_scratch(ctx, (size_t)n * y.total); if (s != MTR_OK) return s;
     std::vector<int32_t> iread, ipass;
-    // Pearson: a pass is cut into position segments (k1_pass_pearson_seg; same segment length as k1_seg_len), item = pass | (segment + 1) << 8
-    const bool segs = !ctx->manhattan && !ctx->file_order;
+    // a pass is cut into position segments (k1_pass_pearson_seg / k1_passes_manhattan; same segment length as k1_seg_len), item = pass | (segment + 1) << 8
+    const bool segs = !ctx->file_order;
     for (int i = 0; i < n; i++) {
         const int L = ctx->lens[(size_t)i], np = k1_num_passes(L);
         const int nn = L + 2 * mtrc_rand_len(L);
@@ -569,7 +569,7 @@ static mtr_status launch_k1_parts(mtr_ctx *ctx)
     // extraction + de-duplication: the passes of a read as a pipeline of 16 wavefronts (the file-order mode keeps one wavefront per
     // read: its passes look at the stale tail)
     if (ctx->file_order) hipLaunchKernelGGL(mtr_k1_part, dim3((unsigned)std::min(n, slots)), dim3(64), 0, ctx->stream, a, (int)K1_FINISH, (const int32_t *)nullptr, (const int32_t *)nullptr, n);
-    else hipLaunchKernelGGL(mtr_k1_finish_pipe, dim3((unsigned)std::min(n, ctx->n_cu)), dim3(64 * K1_PIPE_WAVES), 0, ctx->stream, a, n);
+    else hipLaunchKernelGGL(mtr_k1_finish_pipe, dim3((unsigned)std::min(n, ctx->n_cu)), dim3(64 * K1_PIPE_WAVES), 0, ctx->stream, a, n, segs ? 1 : 0);
     HIPCHK(hipGetLastError());
     return MTR_OK;
 }

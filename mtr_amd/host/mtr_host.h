@@ -116,7 +116,7 @@ typedef struct mtrh_opts {
     size_t chunk_bytes;                    /* 0 = default */
     int   parse_threads, print_threads;    /* 0 = default */
     const char *engine_lib;                /* NULL = default (mtrh_engine_load) */
-    size_t split_bytes;                    /* lpt: a file of at least this many bytes may be spread over several ranks (0 = default 50 000; (size_t)-1 = never) */
+    size_t split_bytes;                    /* lpt: a file of at least this many bytes may be spread over several ranks (0 or (size_t)-1 = never, the default) */
 } mtrh_opts;
 typedef struct mtrh_run mtrh_run;
 /* opens the files, plans the chunks, starts the parser threads and the device thread; NULL + message on stderr on failure */

@@ -22,8 +22,11 @@
 #define RESULT_QUEUE 4
 
 #define MAX_SHARES 16
-#define SPLIT_BYTES_DEFAULT ((size_t)50000)
-#define RANGE_PHASE_SHARE 0.2                   /* part of a long read's work every rank of its group repeats (the candidate ranges) */
+/* Part of a long read's time that every rank of its group spends whatever its share: the candidate ranges (one read = one chain of
+ * passes) AND the critical path of the per-range kernels, which one read cannot fill the GPU with anyway.  Measured on MI355X
+ * (profiles/r03_share_cost.json): a 140 kb read 47.4 ms whole, 41.4 / 41.0 / 40.7 ms as one of 2 / 4 / 8 shares.  Sharing a read
+ * therefore only pays where ranks would otherwise idle, and is opt-in (mtrh_opts.split_bytes, --split-bytes). */
+#define RANGE_PHASE_SHARE 0.85
 typedef struct { int file; size_t begin, end; int owner, round; int n_shares; int shares[MAX_SHARES]; } chunk_t;   /* shares[0] == owner: replays and reports */
 
 struct mtrh_run {
@@ -89,10 +92,10 @@ static void plan(mtrh_run *r)
         double *load = (double *)calloc((size_t)world, sizeof(double));
         for (int c = 0; c < r->n_chunks; c++) ord[c] = &r->chunks[c];
         qsort(ord, (size_t)r->n_chunks, sizeof(chunk_t *), cmp_size_desc);
-        /* A file whose cost exceeds what a rank should get is spread over g ranks: each repeats the candidate ranges (a fifth
-         * of a long read's work) and searches 1/g of them (mtr_run_ranges_share).  g = what brings a share down to the target. */
-        const size_t split_bytes = r->o.split_bytes ? r->o.split_bytes : SPLIT_BYTES_DEFAULT;
-        const int can_split = world > 1 && r->eng.run_share && !r->o.file_order && split_bytes != (size_t)-1;
+        /* On request a file whose cost exceeds what a rank should get is spread over g ranks: each repeats the candidate ranges
+         * and searches 1/g of them (mtr_run_ranges_share).  g = what brings a share down to the target, if anything does. */
+        const size_t split_bytes = r->o.split_bytes;
+        const int can_split = world > 1 && r->eng.run_share && !r->o.file_order && split_bytes != 0 && split_bytes != (size_t)-1;
         double total = 0;
         for (int c = 0; c < r->n_chunks; c++) total += pow((double)(r->chunks[c].end - r->chunks[c].begin), 1.5);
         const double target = total / world;

@@ -92,7 +92,7 @@ def parse_args(argv):
     ap.add_argument("--chunk-bytes", type=int, default=0, help="FASTA bytes per chunk (default 24 MiB)")
     ap.add_argument("--split-bytes", type=int, default=0,
                     help="several files: a file of at least this many bytes whose cost exceeds a rank's fair part is searched by several ranks "
-                         "(default 50000; -1 = never)")
+                         "(default: never - on MI355X a share of a long read takes 86 %% of the whole read's time, DESIGN.md)")
     ap.add_argument("--stats", action="store_true", help="rank 0 reports ranks seen / bytes gathered on stderr")
     ap.add_argument("--force-dist", action="store_true",
                     help="a single rank too joins a process group and goes through the collectives (under torchrun with one rank: RCCL on a one-GPU box)")

@@ -19,5 +19,6 @@ for name in [a for a in sys.argv[1:] if a != "-p"]:
         e.upload(reads)
         t0 = time.perf_counter(); e.run(); dt = time.perf_counter() - t0
     print(name, sum(len(c) for c in reads), "bases", round(dt * 1e3, 2), "ms", {k: round(v, 2) for k, v in e.kernel_times_ms().items()}, flush=True)
-    print("   counters", e.counters() if hasattr(e, "counters") else None)
+    c = e.counters() if hasattr(e, "counters") else {}
+    print("   counters", {k: v for k, v in c.items() if v and not k.startswith("cyc_")})
     e.close()

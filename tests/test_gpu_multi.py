@@ -255,12 +255,12 @@ def test_launcher_spreads_a_long_read_over_ranks():
     from tests.test_run_gloo import SHARED
     for big, mode, flags in (("worm_chrII_1", "p", ["-p"]), ("2_5_10_20_50_100_200_set", "default", []), ("2_5_10_20_50_100_200_set", "a", ["-a"])):
         names = ["3_5", big]
-        p = _run([*flags, *[gu.input_path(n) for n in names]], 2, "gloo")
+        p = _run([*flags, "--split-bytes", "50000", *[gu.input_path(n) for n in names]], 2, "gloo")
         assert p.returncode == 0, p.stderr.decode()[-800:]
         assert p.stdout == b"".join(golden(n, mode) for n in names), (big, mode)
         stats = [l for l in p.stderr.decode().splitlines() if l.startswith("[mtr_amd.run]")][0]
         assert "shared_files=1 " in stats and "max_shares=2 " in stats and "candidate_bytes=0" not in stats, stats
-    p = _run(["-p", *[gu.input_path(n) for n in SHARED]], 4, "gloo")              # both long reads shared, one of them four ways
+    p = _run(["-p", "--split-bytes", "50000", *[gu.input_path(n) for n in SHARED]], 4, "gloo")              # both long reads shared, one of them four ways
     assert p.returncode == 0, p.stderr.decode()[-800:]
     assert p.stdout == b"".join(golden(n, "p") for n in SHARED)
     assert "max_shares=4 " in p.stderr.decode()

@@ -115,14 +115,14 @@ def test_a_long_read_is_searched_by_several_ranks(setup, world, mode, flags, sha
     replays the reference's range loop over them.  The stand-in engine checks that exactly the group's other shares came back."""
     lib, tables = setup
     files = [gu.input_path(n) for n in SHARED]
-    p = run(lib, tables["p" if mode == "p" else "default"], world, [*flags, *files])
+    p = run(lib, tables["p" if mode == "p" else "default"], world, [*flags, "--split-bytes", "50000", *files])
     assert p.returncode == 0, p.stderr.decode()[-800:]
     assert p.stdout == b"".join(golden(n, mode) for n in SHARED)
     stats = [l for l in p.stderr.decode().splitlines() if l.startswith("[mtr_amd.run]")][0]
     print(stats)
     assert "shared_files=0 " not in stats and f"max_shares={shares} " in stats and "candidate_bytes=0" not in stats, stats
-    # --split-bytes -1: nothing is shared, same report
-    q = run(lib, tables["p" if mode == "p" else "default"], world, [*flags, "--split-bytes", "-1", *files])
+    # without --split-bytes (the default): nothing is shared, same report
+    q = run(lib, tables["p" if mode == "p" else "default"], world, [*flags, *files])
     assert q.returncode == 0 and q.stdout == p.stdout
     assert "shared_files=0 " in [l for l in q.stderr.decode().splitlines() if l.startswith("[mtr_amd.run]")][0]
 
@@ -133,7 +133,7 @@ def test_a_share_that_cannot_be_searched_sends_the_read_back_whole(setup, fail_s
     """a share whose search fails (a matrix beyond WrapDPsize, memory) -> the reporting rank runs the read whole, as without sharing"""
     lib, tables = setup
     files = [gu.input_path(n) for n in SHARED]
-    p = run(lib, tables["default"], 2, files, extra_env={"MTR_REPLAY_FAIL_SHARE": str(fail_share)})
+    p = run(lib, tables["default"], 2, ["--split-bytes", "50000", *files], extra_env={"MTR_REPLAY_FAIL_SHARE": str(fail_share)})
     assert p.returncode == 0, p.stderr.decode()[-800:]
     assert p.stdout == b"".join(golden(n, "default") for n in SHARED)
     assert "shared_files=1 " in p.stderr.decode()

@@ -42,15 +42,20 @@ def per_kernel(rows):
 
 
 def kernel_sources_sha():
-    # the sources of the dominant kernel (mtr_k_reads) and the flags it is built with; the host side of the library
-    # (mtr_abi.hip) and the staged mode's kernels (k3_staged.hip.inc) are not part of it
+    # the sources of the kernels and the flags they are built with (the same function as bench.py's)
     h = hashlib.sha256()
     d = os.path.join(ROOT, "mtr_amd", "csrc")
-    for f in ("device_util.hip.inc", "dp_wrap.hip.inc", "k1_ranges.hip.inc", "k2_units.hip.inc", "mtr_common.h", "min_missing_table.h"):
+    for f in ("device_util.hip.inc", "dp_wrap.hip.inc", "dp_quad.hip.inc", "k1_ranges.hip.inc", "k2_units.hip.inc", "k3_staged.hip.inc", "mtr_common.h",
+              "min_missing_table.h", "mtr_abi.hip"):
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     h.update(open(os.path.join(ROOT, "mtr_amd", "build.py"), "rb").read())
     return h.hexdigest()[:16]
+
+
+# one launch = the staged chain: every kernel of the library except the per-read kernel (bench.py runs it ONCE, outside the timed
+# region, for the reference's work counters) and the wire-form kernels of the fetch
+NOT_CHAIN = ("mtr_k_reads", "mtr_k_wire")
 
 
 def main():
@@ -69,40 +74,65 @@ def main():
         with open(os.path.join(out, "bench_trace.json")) as fh:
             b = json.loads(fh.read().strip().splitlines()[-1])
         s["bench_under_rocprof"] = {"value": b["value"], "ms_per_step": b["ms_per_step"], "kernels_ms": b["kernels_ms"],
-                                    "kernels_ms_alone": b.get("kernels_ms_alone"), "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"],
-                                    "cells_per_launch": b["roofline"]["valu"]["cells_per_launch"]}
+                                    "kernels_ms_alone": b.get("kernels_ms_alone"), "algorithmic_bytes_per_launch": b["roofline"]["hbm"]["algorithmic_bytes_per_launch"],
+                                    "cells_per_launch": b["roofline"]["cells_per_launch"], "reads_per_launch": b.get("config", {}).get("reads_per_step")}
     except Exception as e:      # noqa: BLE001
         s["bench_under_rocprof"] = f"unreadable: {e}"
     groups = {g: per_kernel(counter_rows(os.path.join(out, g))) for g in ("fetch", "write", "sq1", "sq2", "lds")}
     s["counters_per_launch"] = groups
-    dom = max(dur_ms, key=dur_ms.get) if dur_ms else None
+    chain = [k for k in dur_ms if not k.startswith(NOT_CHAIN)]
+    dom = max(chain, key=dur_ms.get) if chain else None
     s["dominant_kernel"] = dom
     if dom:
-        g = lambda grp, c: groups.get(grp, {}).get(dom, {}).get(c)      # noqa: E731
-        f, w = g("fetch", "FETCH_SIZE"), g("write", "WRITE_SIZE")
+        def launches(grp):            # launches of the chain seen by a counter pass = dispatches of a kernel that runs once per launch
+            return max(1, int(groups.get(grp, {}).get("mtr_k_gather", {}).get("_launches", 1)))
+
+        def total(grp, c):            # per launch of the chain: sum over its kernels of (mean per dispatch x dispatches) / launches
+            t, seen = 0.0, False
+            for k, cs in groups.get(grp, {}).items():
+                if k.startswith(NOT_CHAIN) or c not in cs:
+                    continue
+                t += cs[c] * cs["_launches"] / launches(grp); seen = True
+            return t if seen else None
+
+        table = {}
+        calls = {r["Name"].split("(")[0].replace("void ", ""): int(r["Calls"]) for r in s.get("kernel_stats", [])}
+        n_launch_trace = max(1, calls.get("mtr_k_gather", 1))
+        for k in sorted(chain, key=lambda k: -dur_ms[k] * calls.get(k, 1)):
+            row = {"ms_per_launch": dur_ms[k] * calls.get(k, 1) / n_launch_trace}
+            for grp, c, key, mul in (("sq2", "SQ_INSTS_VALU", "valu", 1.0), ("sq2", "SQ_INSTS_SALU", "salu", 1.0), ("fetch", "FETCH_SIZE", "fetch_bytes", 1024.0),
+                                     ("write", "WRITE_SIZE", "write_bytes", 1024.0), ("sq1", "SQ_WAVE_CYCLES", "wave_cycles", 4.0)):
+                cs = groups.get(grp, {}).get(k, {})
+                if c in cs:
+                    row[key] = cs[c] * cs["_launches"] / launches(grp) * mul
+            table[k] = row
+        s["chain_per_launch"] = table
+        s["chain_ms_per_launch_kernels_one_at_a_time"] = sum(r["ms_per_launch"] for r in table.values())
+        f, w = total("fetch", "FETCH_SIZE"), total("write", "WRITE_SIZE")
         if f is not None and w is not None:
             s["k2_fetch_bytes_per_launch"] = f * 1024.0
             s["k2_write_bytes_per_launch"] = w * 1024.0
             s["k2_hbm_bytes_per_launch"] = (f + w) * 1024.0
             s["k2_hbm_bytes_per_launch_fetch_x2"] = (2 * f + w) * 1024.0
-        valu, salu = g("sq2", "SQ_INSTS_VALU"), g("sq2", "SQ_INSTS_SALU")
+        valu, salu = total("sq2", "SQ_INSTS_VALU"), total("sq2", "SQ_INSTS_SALU")
         if valu:
             simds, clock = 1024, 2.4e9
-            s["valu_issue_utilisation"] = valu * 2.0 / (simds * dur_ms[dom] * 1e-3 * clock)
+            s["SQ_INSTS_VALU_per_launch"] = valu
+            s["valu_issue_utilisation"] = valu * 2.0 / (simds * s["chain_ms_per_launch_kernels_one_at_a_time"] * 1e-3 * clock)
             s["insts_valu_plus_salu"] = valu + (salu or 0.0)
             cells = s["bench_under_rocprof"].get("cells_per_launch") if isinstance(s["bench_under_rocprof"], dict) else None
             if cells:
                 s["lanes_doing_reference_work"] = cells * 7.0 / (valu * 64.0)
                 s["cells_per_instruction"] = cells / (valu + (salu or 0.0))
-        bc, ia = g("lds", "SQ_LDS_BANK_CONFLICT"), g("lds", "SQ_LDS_IDX_ACTIVE")
+        bc, ia = total("lds", "SQ_LDS_BANK_CONFLICT"), total("lds", "SQ_LDS_IDX_ACTIVE")
         if bc is not None and ia:
             s["lds_bank_conflict_share_of_lds_cycles"] = bc / ia
-            wc = g("sq1", "SQ_WAVE_CYCLES")
+            wc = total("sq1", "SQ_WAVE_CYCLES")
             if wc:
                 s["lds_array_busy_share_of_wave_cycles"] = ia / (4.0 * wc)
     with open(os.path.join(out, "summary.json"), "w") as fh:
         json.dump(s, fh, indent=1)
-    print(json.dumps({k: v for k, v in s.items() if k not in ("kernel_stats", "counters_per_launch")}))
+    print(json.dumps({k: v for k, v in s.items() if k not in ("kernel_stats", "counters_per_launch", "chain_per_launch")}))
 
 
 if __name__ == "__main__":

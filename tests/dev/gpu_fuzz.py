@@ -74,12 +74,21 @@ def main():
                 for i, w in zip(order[j::56], ch):
                     want[i] = w
             t_or = time.time() - t0
+            # "batches of 100": the range finder of few reads (one wavefront per (read, pass, segment), the passes of a read as a
+            # pipeline of 16 wavefronts, mtr_k1_finish_pipe) instead of one wavefront per read
             modes = {"per-read": dict(MTR_STAGED="0", MTR_QUAD_MIN="0"), "staged": dict(MTR_STAGED="1", MTR_QUAD_MIN="0"),
-                     "staged+quads": dict(MTR_STAGED="1", MTR_QUAD_MIN="1")}
+                     "staged+quads": dict(MTR_STAGED="1", MTR_QUAD_MIN="1"), "staged, batches of 100": dict(MTR_STAGED="1", MTR_QUAD_MIN="0")}
             for split in modes:
                 os.environ.update(modes[split])
                 eng = mtr_amd.Engine(manhattan=manhattan)
-                t0 = time.time(); got = eng.process(reads); t_gpu = time.time() - t0
+                t0 = time.time()
+                if "batches" in split:
+                    got = []
+                    for b in range(0, len(reads), 100):
+                        got += eng.process(reads[b:b + 100])
+                else:
+                    got = eng.process(reads)
+                t_gpu = time.time() - t0
                 bad = [i for i in range(len(reads)) if [tuple(r) for r in got[i]] != want[i]]
                 bad_total += len(bad)
                 print(f"seed {seed} {'manhattan' if manhattan else 'pearson  '} {split}: {len(reads)} reads ({sum(map(len, reads)) / 1e6:.1f} Mb, "

@@ -71,6 +71,7 @@ struct mtr_ctx {
     long long st_last_arena_cap = 0;
     int32_t st_cand_cap = 0;
     int32_t share = 0, n_shares = 1;   // mtr_run_ranges_share: this context searches the ranges t % n_shares == share of every read
+    int st_last_nsub = 1;              // sub-lists of the chain's last launch (the arena's cursors are read after an overflow)
     bool skip_replay = false;          // mtr_run_ranges_share: the chain stops before mtr_k_replay
     bool cand_ready = false;           // a share run has left its candidate records on the device (mtr_export_candidates / mtr_replay_candidates)
     int64_t st_n_items = 0;            // candidate ranges of the resident batch (work items of the chain)
@@ -690,6 +691,8 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     s.dp_cap = (int32_t)std::min<int64_t>(0x7fffff00, sumL / 8 + 4096);
     s.sorted_cap = s.dp_cap + 4 * ST_QCLASSES;
     s.cand_cap = (int32_t)std::min<int64_t>(0x7fffff00, (int64_t)n * 8 + sumL / 256 + 1024);
+    // lists in 64 sub-lists with a counter each from 4 M bases (k3_staged.hip.inc: one counter completes 88 M appends a second)
+    s.nsub = sumL >= (4 << 20) ? 64 : 1;
     long test_rev_cap = -1, test_cont_cap = -1;
     if (const char *e = getenv("MTR_TEST_STAGED_CAPS")) {
         // tests only: "arena=<bytes>,kc=<n>,dp=<n>,cand=<n>,cont=<n>,rev=<n>" shrinks capacities so that every overflow path of the
@@ -700,6 +703,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         if (cap("dp=") >= 0) s.dp_cap = (int32_t)cap("dp=");
         if (cap("cand=") >= 0) s.cand_cap = (int32_t)cap("cand=");
         test_cont_cap = cap("cont="); test_rev_cap = cap("rev=");
+        if (cap("nsub=") == 1 || cap("nsub=") == 64) s.nsub = (int32_t)cap("nsub=");
         s.sorted_cap = s.dp_cap + 4 * ST_QCLASSES;
     }
     ST_ALLOC(ensure_dev(ctx, ctx->d_st_arena, (size_t)s.arena_cap));
@@ -727,7 +731,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     s.rev_items = (long long *)ctx->d_st_rev;
     unsigned long long *sc = ctx->d_st_scalars;
     s.item_off = ctx->d_item_off; s.n_items = (int32_t *)(sc + 0 * 32);
-    s.arena = ctx->d_st_arena; s.arena_cur = sc + 1 * 32; ctx->st_last_arena_cap = s.arena_cap;
+    s.arena = ctx->d_st_arena; s.arena_cur = sc + 1 * 32; ctx->st_last_arena_cap = s.arena_cap; ctx->st_last_nsub = s.nsub;
     s.kc_items = (long long *)ctx->d_st_kc; s.n_kc = (unsigned *)(sc + 2 * 32);
     s.dp = ctx->d_st_dp; s.n_dp = (unsigned *)(sc + 3 * 32);
     s.bin_count = ctx->d_st_bincnt; s.dp_bin = ctx->d_st_dpbin; s.dp_rank = ctx->d_st_dprank;
@@ -1012,18 +1016,31 @@ extern "C" mtr_status mtr_wait(mtr_ctx *ctx)
     mtr_status st = check_status(ctx);
     if (ctx->last_staged && dbg()) {
         unsigned long long sc[40 * 32]; int32_t cw[10];
-        if (copy_sync(ctx, sc, ctx->d_st_scalars, sizeof sc, hipMemcpyDeviceToHost) == hipSuccess && copy_sync(ctx, cw, ctx->d_st_classwave, sizeof cw, hipMemcpyDeviceToHost) == hipSuccess)
-            DBG("staged: items %d, ranges with a block %u (+ %u per-k work items), DP items %u (%u work-list entries of one wavefront each), candidate arena %.1f MB, records parked %u; alignments four per wavefront: %d slots (8..1 columns per lane: %d %d %d %d %d %d %d %d)",
-                (int)(int32_t)sc[0], (unsigned)sc[2 * 32], st_sum(sc + 24 * 32), (unsigned)sc[3 * 32], st_sum(sc + 16 * 32), (double)sc[1 * 32] / 1e6, (unsigned)sc[5 * 32], cw[8], cw[1] - cw[0], cw[2] - cw[1], cw[3] - cw[2], cw[4] - cw[3], cw[5] - cw[4], cw[6] - cw[5], cw[7] - cw[6], cw[8] - cw[7]);
+        std::vector<unsigned> wk((size_t)ST_N_QUEUES * WQ_WORDS);   // the sub-list counters live in work-queue slots (k3_staged.hip.inc: ST_SL_*)
+        auto sub_sum = [&](int slot, bool wide) { unsigned long long t = 0; for (int q = 0; q < WQ_MAX; q++) { const unsigned *p = wk.data() + (size_t)slot * WQ_WORDS + (size_t)q * WQ_STRIDE; t += wide ? *(const unsigned long long *)p : (unsigned long long)*p; } return t; };
+        if (copy_sync(ctx, sc, ctx->d_st_scalars, sizeof sc, hipMemcpyDeviceToHost) == hipSuccess && copy_sync(ctx, cw, ctx->d_st_classwave, sizeof cw, hipMemcpyDeviceToHost) == hipSuccess
+            && copy_sync(ctx, wk.data(), (const uint8_t *)ctx->d_st_scalars + 64 * 256, wk.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long n_cont = 0;
+            for (int slot : { 6, 7, 9, 11, 12, 13, 14, 15 }) n_cont += sub_sum(slot, false);
+            unsigned long long n_wv = 0;
+            for (int cls = 0; cls < ST_NCLS; cls++) n_wv += sub_sum(ST_SL_WV + cls, false);
+            DBG("staged: items %d, ranges with a block %llu (+ %llu per-k work items), DP items %llu (%u work-list entries of one wavefront each), candidate arena %.1f MB, records parked %u; alignments four per wavefront: %d slots (8..1 columns per lane: %d %d %d %d %d %d %d %d)",
+                (int)(int32_t)sc[0], sub_sum(3, false), n_cont, sub_sum(1, false), (unsigned)n_wv, (double)sub_sum(2, true) / 1e6, (unsigned)sc[5 * 32], cw[8], cw[1] - cw[0], cw[2] - cw[1], cw[3] - cw[2], cw[4] - cw[3], cw[5] - cw[4], cw[6] - cw[5], cw[7] - cw[6], cw[8] - cw[7]);
+        }
     }
     if (st == MTR_ERR_OVERFLOW && ctx->last_staged) {
         // the batch outgrew a buffer of the staged mode: the per-read kernel takes it (same results)
         int32_t dst = 0;
         HIPCHK(copy_sync(ctx, &dst, ctx->d_status, 4, hipMemcpyDeviceToHost));
         if (dst == DEV_ERR_STAGED_OVERFLOW) {
-            unsigned long long used = 0;
-            (void)copy_sync(ctx, &used, ctx->d_st_scalars + 1 * 32, sizeof used, hipMemcpyDeviceToHost);
-            const bool arena_full = ctx->d_st_arena && used > ctx->st_last_arena_cap && ctx->st_arena_per_base < 1024 && !getenv("MTR_TEST_STAGED_CAPS");
+            // the arena is full when one of its sub-arenas is (k3_staged.hip.inc: st_reserve_bytes; 64-bit cursors in work-queue slot 2)
+            unsigned long long used = 0, worst = 0;
+            {
+                std::vector<unsigned> wk((size_t)WQ_WORDS);
+                (void)copy_sync(ctx, wk.data(), (const uint8_t *)ctx->d_st_scalars + 64 * 256 + (size_t)2 * WQ_WORDS * 4, wk.size() * 4, hipMemcpyDeviceToHost);
+                for (int q = 0; q < ctx->st_last_nsub; q++) { const unsigned long long u = *(const unsigned long long *)(wk.data() + (size_t)q * WQ_STRIDE); used += u; worst = std::max(worst, u); }
+            }
+            const bool arena_full = ctx->d_st_arena && worst > (unsigned long long)((ctx->st_last_arena_cap / ctx->st_last_nsub) & ~15ll) && ctx->st_arena_per_base < 1024 && !getenv("MTR_TEST_STAGED_CAPS");
             if (arena_full) ctx->st_arena_per_base *= 4;
             DBG("staged chain: a buffer overflowed (candidate arena %.1f of %.1f MB): %s", (double)used / 1e6, (double)ctx->st_last_arena_cap / 1e6,
                 arena_full ? "once more with four times the arena per base" : "running the batch with the per-read kernel");

@@ -265,6 +265,9 @@ def test_read_of_the_maximum_length(eng, oracle):
 # ---- the kernel modes: same records as one wavefront per read -----------------------------------------------------------
 MODES = {"per_read": {"MTR_STAGED": "0"},
          "staged": {"MTR_STAGED": "1", "MTR_QUAD_MIN": "0"}, "staged_quads": {"MTR_STAGED": "1", "MTR_QUAD_MIN": "1"},
+         # the lists of a big batch in 64 sub-lists with a counter each (k3_staged.hip.inc), forced on a small one
+         "staged_sublists": {"MTR_STAGED": "1", "MTR_QUAD_MIN": "0", "MTR_TEST_STAGED_CAPS": "nsub=64"},
+         "staged_sublists_quads": {"MTR_STAGED": "1", "MTR_QUAD_MIN": "1", "MTR_TEST_STAGED_CAPS": "nsub=64"},
          "staged_overflow_arena": {"MTR_STAGED": "1", "MTR_TEST_STAGED_CAPS": "arena=200000"},
          "staged_overflow_kc": {"MTR_STAGED": "1", "MTR_TEST_STAGED_CAPS": "kc=40"},
          "staged_overflow_cont": {"MTR_STAGED": "1", "MTR_TEST_STAGED_CAPS": "cont=10"},

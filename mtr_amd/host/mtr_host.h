@@ -13,10 +13,29 @@
  */
 #ifndef MTR_HOST_H
 #define MTR_HOST_H
+#include <setjmp.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #include "mtr_hip.h"
+
+/* ---- allocation (alloc.c): never returns NULL; a worker thread that cannot allocate jumps to its entry function ------------- */
+enum { MTRH_THREAD_MAIN = 0, MTRH_THREAD_PARSER, MTRH_THREAD_DEVICE, MTRH_THREAD_PRINTER };
+extern __thread jmp_buf *mtrh_oom_target;      /* where mtrh_oom() jumps to in this thread (NULL: print and exit, like the reference) */
+extern __thread int mtrh_thread_kind;
+void  mtrh_oom(size_t bytes) __attribute__((noreturn));
+void *mtrh_xmalloc(size_t n);
+void *mtrh_xcalloc(size_t n, size_t m);
+void *mtrh_xrealloc(void *p, size_t n);
+char *mtrh_xstrdup(const char *s);
+#ifndef MTRH_NO_ALLOC_WRAP
+#define malloc(n) mtrh_xmalloc(n)
+#define calloc(n, m) mtrh_xcalloc(n, m)
+#define realloc(p, n) mtrh_xrealloc(p, n)
+#define strdup(s) mtrh_xstrdup(s)
+#endif
 
 #define MTRH_BLK 4096                 /* fgets chunk of the reference reader (mTR.h:57) */
 #define MTRH_OVERLAP 10               /* MAX_LEN_overlapping (mTR.h:39) */

@@ -42,6 +42,8 @@ struct mtrh_run {
     double t_parse_wait, t_submit, t_fetch, t_kernel; long long queries;
     int overlap;                                   /* more than one device batch: launches of the two contexts overlap */
     /* long reads spread over ranks (lpt) */
+    int parse_failed;                              /* a parser thread could not allocate: the device thread reports it */
+    int *chunk_done;                               /* per chunk: its last result has been handed on */
     int has_split;
     uint8_t *cand_out; size_t cand_out_bytes; int cand_out_ready;       /* round 0: this rank's candidate records, [chunk, share, bytes | -1][blob] ... */
     uint8_t **fed; size_t *fed_bytes; int n_fed, fed_ready;             /* what the launcher all-gathered and handed back */
@@ -131,6 +133,17 @@ static void plan(mtrh_run *r)
 static void *parser_main(void *arg)
 {
     mtrh_run *r = (mtrh_run *)arg;
+    jmp_buf oom;
+    mtrh_thread_kind = MTRH_THREAD_PARSER;
+    if (setjmp(oom)) {                                   /* an allocation of this thread failed (alloc.c): the device thread says so */
+        mtrh_oom_target = NULL;
+        pthread_mutex_lock(&r->mu);
+        r->parse_failed = 1;
+        pthread_cond_broadcast(&r->cv_parse);
+        pthread_mutex_unlock(&r->mu);
+        return NULL;
+    }
+    mtrh_oom_target = &oom;
     for (;;) {
         pthread_mutex_lock(&r->mu);
         while (!r->stopping && r->next_parse < r->n_list && r->next_parse >= r->consumed + PARSE_AHEAD + r->n_parsers) pthread_cond_wait(&r->cv_parse, &r->mu);
@@ -158,6 +171,7 @@ void mtrh_result_free(mtrh_result *x)
 static void push_result(mtrh_run *r, mtrh_result *x)
 {
     pthread_mutex_lock(&r->mu);
+    if (x->last_of_chunk && x->chunk >= 0 && x->chunk < r->n_chunks) r->chunk_done[x->chunk] = 1;
     while (r->q_n == RESULT_QUEUE && !r->stopping) pthread_cond_wait(&r->cv_res, &r->mu);
     if (r->stopping) { pthread_mutex_unlock(&r->mu); mtrh_result_free(x); return; }
     r->queue[(r->q_head + r->q_n) % RESULT_QUEUE] = x; r->q_n++;
@@ -293,9 +307,48 @@ static void blob_append(uint8_t **out, size_t *n, size_t *cap, const void *src, 
 /* what a rank keeps of a read it shares and will report (it holds share 0) between the two halves */
 typedef struct { int list_idx; mtr_ctx *ctx; mtrh_batch *batch; int ok; } split_job;
 
+/* after a failed allocation (this thread's or a parser's): every chunk this rank reports and has not finished gets a result that
+ * carries the message - what is printed before it stays printed, the run ends with status 1, and no rank waits for a chunk forever */
+static void report_failure(mtrh_run *r, const char *msg)
+{
+    for (int c = 0; c < r->n_chunks; c++) {
+        if (r->chunks[c].owner != r->o.rank) continue;
+        pthread_mutex_lock(&r->mu);
+        const int done = r->chunk_done[c], stopping = r->stopping;
+        pthread_mutex_unlock(&r->mu);
+        if (done) continue;
+        if (stopping) break;
+        mtrh_result *x = (mtrh_result *)calloc(1, sizeof *x);
+        x->chunk = c; x->file_idx = r->chunks[c].file; x->batch = (mtrh_batch *)calloc(1, sizeof(mtrh_batch)); x->last_of_chunk = 1;
+        x->counts = (int32_t *)calloc(1, sizeof(int32_t));
+        x->fatal = 1; x->fatal_msg = strdup(msg);
+        push_result(r, x);
+    }
+}
+
+static void device_body(mtrh_run *r);
 static void *device_main(void *arg)
 {
     mtrh_run *r = (mtrh_run *)arg;
+    jmp_buf oom;
+    mtrh_thread_kind = MTRH_THREAD_DEVICE;
+    if (setjmp(oom)) {                                   /* an allocation of this thread failed (alloc.c) */
+        mtrh_oom_target = NULL;
+        report_failure(r, "fatal error: cannot allocate memory");
+    } else {
+        mtrh_oom_target = &oom;
+        device_body(r);
+        mtrh_oom_target = NULL;
+    }
+    pthread_mutex_lock(&r->mu);
+    r->device_done = 1;
+    pthread_cond_broadcast(&r->cv_res);
+    pthread_mutex_unlock(&r->mu);
+    return NULL;
+}
+
+static void device_body(mtrh_run *r)
+{
     /* Two contexts = two device batches in flight.  The second one is created when a second batch shows up. */
     mtr_ctx *ctxs[2] = { NULL, NULL };
     mtr_file_state *fs = NULL;
@@ -316,7 +369,8 @@ static void *device_main(void *arg)
             if (c->n_shares <= 1) continue;
             const int share = share_of(c, r->o.rank);
             pthread_mutex_lock(&r->mu);
-            while (!r->pstate[idx] && !r->stopping) pthread_cond_wait(&r->cv_parse, &r->mu);
+            while (!r->pstate[idx] && !r->stopping && !r->parse_failed) pthread_cond_wait(&r->cv_parse, &r->mu);
+            if (!r->pstate[idx] && r->parse_failed && !r->stopping) { pthread_mutex_unlock(&r->mu); mtrh_oom(0); }     /* (reported like this thread's own failure) */
             mtrh_batch *b = r->parsed[idx];
             r->parsed[idx] = NULL;                              /* (the reporting rank keeps the batch in its job for the second half) */
             r->consumed = idx + 1;
@@ -358,7 +412,12 @@ static void *device_main(void *arg)
         if (r->chunks[r->list[idx]].n_shares > 1) continue;            /* (handled above and below) */
         double t0 = now_s();
         pthread_mutex_lock(&r->mu);
-        while (!r->pstate[idx] && !r->stopping) pthread_cond_wait(&r->cv_parse, &r->mu);
+        while (!r->pstate[idx] && !r->stopping && !r->parse_failed) pthread_cond_wait(&r->cv_parse, &r->mu);
+        if (!r->pstate[idx] && r->parse_failed && !r->stopping) {
+            pthread_mutex_unlock(&r->mu);
+            if (prev) { finish_batch(r, prev_ctx, prev); prev = NULL; }       /* what is on the device is reported first */
+            mtrh_oom(0);
+        }
         mtrh_batch *b = r->parsed[idx]; r->parsed[idx] = NULL;
         r->consumed = idx + 1;
         pthread_cond_broadcast(&r->cv_parse);
@@ -504,11 +563,6 @@ static void *device_main(void *arg)
     for (int t = 0; t < 2; t++) if (ctxs[t]) r->eng.destroy(ctxs[t]);
     mtrh_stamp("device contexts destroyed");
     free(file_ended); free(dead_msg);
-    pthread_mutex_lock(&r->mu);
-    r->device_done = 1;
-    pthread_cond_broadcast(&r->cv_res);
-    pthread_mutex_unlock(&r->mu);
-    return NULL;
 }
 
 /* ---- start / stop ------------------------------------------------------------------------------------------------------- */
@@ -535,6 +589,7 @@ mtrh_run *mtrh_run_start(const mtrh_opts *o, const char *const *paths, int n_pat
     for (int c = 0; c <= last_owned; c++) if (r->chunks[c].n_shares <= 1 && (share_of(&r->chunks[c], r->o.rank) >= 0 || r->o.file_order)) r->list[r->n_list++] = c;
     r->parsed = (mtrh_batch **)calloc((size_t)r->n_list + 1, sizeof(mtrh_batch *));
     r->pstate = (int *)calloc((size_t)r->n_list + 1, sizeof(int));
+    r->chunk_done = (int *)calloc((size_t)r->n_chunks + 1, sizeof(int));
     pthread_mutex_init(&r->mu, NULL); pthread_cond_init(&r->cv_parse, NULL); pthread_cond_init(&r->cv_res, NULL);
     int np = o->parse_threads;
     if (np <= 0) { long nc = sysconf(_SC_NPROCESSORS_ONLN); np = nc >= 8 ? 4 : (nc >= 4 ? 2 : 1); }
@@ -604,6 +659,6 @@ void mtrh_run_stop(mtrh_run *r)
     pthread_mutex_destroy(&r->mu); pthread_cond_destroy(&r->cv_parse); pthread_cond_destroy(&r->cv_res);
     for (int k = 0; k < r->n_fed; k++) free(r->fed[k]);
     free(r->fed); free(r->fed_bytes); free(r->cand_out);
-    free(r->files); free(r->chunks); free(r->list); free(r->parsed); free(r->pstate);
+    free(r->files); free(r->chunks); free(r->list); free(r->parsed); free(r->pstate); free(r->chunk_done);
     free(r);
 }

@@ -187,6 +187,7 @@ struct mtrh_printer {
     /* the result being formatted */
     fmt_ctx job; int n_slices, next_slice, done_slices; int slice_first[MAX_PRINT_THREADS * 4 + 1]; tbuf slice_buf[MAX_PRINT_THREADS * 4];
     int pool_exit;
+    int oom;                                           /* a thread of the pool could not allocate while it formatted a slice */
     int status, ended, cur_file; double t_chain;
 };
 
@@ -195,14 +196,19 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
 static void *pool_main(void *arg)
 {
     mtrh_printer *p = (mtrh_printer *)arg;
+    mtrh_thread_kind = MTRH_THREAD_PRINTER;
     pthread_mutex_lock(&p->mu);
     for (;;) {
         while (!p->pool_exit && p->next_slice >= p->n_slices) pthread_cond_wait(&p->cv_job, &p->mu);
         if (p->pool_exit) break;
         const int s = p->next_slice++;
         pthread_mutex_unlock(&p->mu);
-        format_reads(&p->job, p->slice_first[s], p->slice_first[s + 1], &p->slice_buf[s]);
+        jmp_buf oom;                                   /* (alloc.c: a failed allocation inside format_reads comes back here) */
+        const int failed = setjmp(oom);
+        if (!failed) { mtrh_oom_target = &oom; format_reads(&p->job, p->slice_first[s], p->slice_first[s + 1], &p->slice_buf[s]); }
+        mtrh_oom_target = NULL;
         pthread_mutex_lock(&p->mu);
+        if (failed) p->oom = 1;
         if (++p->done_slices == p->n_slices) pthread_cond_broadcast(&p->cv_done);
     }
     pthread_mutex_unlock(&p->mu);
@@ -246,7 +252,9 @@ static void print_one(mtrh_printer *p, mtrh_result *r)
         p->n_slices = slices; p->next_slice = 0;
         pthread_cond_broadcast(&p->cv_job);
         while (p->done_slices < slices) pthread_cond_wait(&p->cv_done, &p->mu);
+        const int pool_failed = p->oom;
         pthread_mutex_unlock(&p->mu);
+        if (pool_failed) { free((void *)f.starts); free(cf); mtrh_oom(0); }       /* (reported by manager_main like its own failure) */
         for (int s = 0; s < slices; s++) if (p->slice_buf[s].n) fwrite(p->slice_buf[s].s, 1, p->slice_buf[s].n, p->out);
     }
     free((void *)f.starts); free(cf);
@@ -266,6 +274,7 @@ static void print_one(mtrh_printer *p, mtrh_result *r)
 static void *manager_main(void *arg)
 {
     mtrh_printer *p = (mtrh_printer *)arg;
+    mtrh_thread_kind = MTRH_THREAD_PRINTER;
     for (;;) {
         pthread_mutex_lock(&p->mu);
         while (!p->head && !p->closing) pthread_cond_wait(&p->cv_q, &p->mu);
@@ -276,7 +285,12 @@ static void *manager_main(void *arg)
         pthread_cond_broadcast(&p->cv_q);
         pthread_mutex_unlock(&p->mu);
         if (q->r->file_idx != p->cur_file) { p->cur_file = q->r->file_idx; p->ended = 0; }    /* every file is a run of its own */
-        if (!p->ended) print_one(p, q->r);
+        if (!p->ended) {
+            jmp_buf oom;                               /* (alloc.c) the printer could not allocate: what is out stays out, the run ends with status 1 */
+            if (setjmp(oom) == 0) { mtrh_oom_target = &oom; print_one(p, q->r); }
+            else { fflush(p->out); fprintf(stderr, "fatal error: cannot allocate memory\n"); p->status = 1; p->ended = 1; }
+            mtrh_oom_target = NULL;
+        }
         mtrh_result_free(q->r);
         free(q);
     }

@@ -264,3 +264,15 @@ def test_an_overlong_record_at_the_start_of_a_chunk_names_the_record_before_it(c
     assert C.string_at(bb.end_id, bb.end_id_len) == b"second"
     lib.mtrh_batch_free(head)
     lib.mtrh_file_close(C.byref(f))
+
+
+@pytest.mark.parametrize("where,n", [("parser", 3), ("parser", 8), ("device", 2), ("device", 4), ("printer", 1), ("printer", 2)])
+def test_a_failed_allocation_in_a_worker_thread_ends_the_run_like_a_device_error(cli, tables, tmp_path, where, n):
+    """alloc.c: the n-th allocation of a parser / device / printer thread fails (MTR_TEST_FAIL_ALLOC).  No exit() inside the thread and
+    no hang: what was printed before is a prefix of the reference's stdout, the message is on stderr, the status is 1."""
+    want = open(os.path.join(gu.GOLDEN, "synth_c4.default.stdout"), "rb").read()
+    env = dict(hu.replay_env(tables["default"]), MTR_TEST_FAIL_ALLOC=f"{where}:{n}")
+    p = subprocess.run([cli, gu.input_path("synth_c4")], capture_output=True, env=env, timeout=60)
+    assert p.returncode == 1, (p.returncode, p.stderr.decode()[-300:])
+    assert b"cannot allocate" in p.stderr
+    assert want.startswith(p.stdout) and len(p.stdout) < len(want)

@@ -137,3 +137,15 @@ def test_a_share_that_cannot_be_searched_sends_the_read_back_whole(setup, fail_s
     assert p.returncode == 0, p.stderr.decode()[-800:]
     assert p.stdout == b"".join(golden(n, "default") for n in SHARED)
     assert "shared_files=1 " in p.stderr.decode()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("where", ["parser:3", "device:2"])
+def test_a_failed_allocation_on_a_rank_ends_every_rank(setup, where):
+    """mtr_amd/host/alloc.c: a worker thread that cannot allocate reports it through the result path (no exit() inside the thread):
+    the message reaches rank 0 with the round, the job ends with status 1 and no rank is left waiting in a collective"""
+    lib, tables = setup
+    p = run(lib, tables["default"], 2, ["--chunk-bytes", "9000", gu.input_path("synth_c4")], extra_env={"MTR_TEST_FAIL_ALLOC": where})
+    assert p.returncode == 1, (p.returncode, p.stderr.decode()[-500:])
+    assert b"cannot allocate" in p.stderr
+    assert golden("synth_c4", "default").startswith(p.stdout)

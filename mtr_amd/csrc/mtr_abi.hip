@@ -731,13 +731,13 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     s.rev_items = (long long *)ctx->d_st_rev;
     unsigned long long *sc = ctx->d_st_scalars;
     s.item_off = ctx->d_item_off; s.n_items = (int32_t *)(sc + 0 * 32);
-    s.arena = ctx->d_st_arena; s.arena_cur = sc + 1 * 32; ctx->st_last_arena_cap = s.arena_cap; ctx->st_last_nsub = s.nsub;
-    s.kc_items = (long long *)ctx->d_st_kc; s.n_kc = (unsigned *)(sc + 2 * 32);
-    s.dp = ctx->d_st_dp; s.n_dp = (unsigned *)(sc + 3 * 32);
+    s.arena = ctx->d_st_arena; ctx->st_last_arena_cap = s.arena_cap; ctx->st_last_nsub = s.nsub;
+    s.kc_items = (long long *)ctx->d_st_kc;
+    s.dp = ctx->d_st_dp;
     s.bin_count = ctx->d_st_bincnt; s.dp_bin = ctx->d_st_dpbin; s.dp_rank = ctx->d_st_dprank;
     s.bin_start = ctx->d_st_binstart; s.sorted = ctx->d_st_sorted; s.quad_cls = ctx->d_st_classwave;
     s.cand = ctx->d_st_cand; s.n_cand = (unsigned *)(sc + 5 * 32); s.cand_flag = ctx->d_st_flag;
-    s.n_wv = (unsigned *)(sc + 16 * 32); s.n_cont = (unsigned *)(sc + 24 * 32); s.n_rev = (unsigned *)(sc + 32 * 32);   // ST_NCLS counters each, 256 bytes apart
+    s.n_rev = (unsigned *)(sc + 32 * 32);   // ST_NCLS counters, 256 bytes apart
     s.work = (unsigned *)(sc + 64 * 32);
     K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
     // few reads: the range finder as one wavefront per (read, pass) over per-READ scratch (launch_k1_parts), as in the

@@ -268,6 +268,7 @@ MODES = {"per_read": {"MTR_STAGED": "0"},
          # the lists of a big batch in 64 sub-lists with a counter each (k3_staged.hip.inc), forced on a small one
          "staged_sublists": {"MTR_STAGED": "1", "MTR_QUAD_MIN": "0", "MTR_TEST_STAGED_CAPS": "nsub=64"},
          "staged_sublists_quads": {"MTR_STAGED": "1", "MTR_QUAD_MIN": "1", "MTR_TEST_STAGED_CAPS": "nsub=64"},
+         "staged_overflow_sublist": {"MTR_STAGED": "1", "MTR_TEST_STAGED_CAPS": "nsub=64,kc=640"},       # 10 blocks per sub-list
          "staged_overflow_arena": {"MTR_STAGED": "1", "MTR_TEST_STAGED_CAPS": "arena=200000"},
          "staged_overflow_kc": {"MTR_STAGED": "1", "MTR_TEST_STAGED_CAPS": "kc=40"},
          "staged_overflow_cont": {"MTR_STAGED": "1", "MTR_TEST_STAGED_CAPS": "cont=10"},

@@ -342,12 +342,16 @@ def main():
 
     # the REFERENCE's work on this batch (its DP calls and cells, what it answers from a repeated call included): one launch of the
     # per-read kernel, which runs the reference's own sequential range loop (the chain also searches ranges that loop removes)
+    staged_before = os.environ.get("MTR_STAGED")
     os.environ["MTR_STAGED"] = "0"
     try:
         engs[0].run()
         ref_cnt = engs[0].counters()
     finally:
-        del os.environ["MTR_STAGED"]
+        if staged_before is None:
+            del os.environ["MTR_STAGED"]
+        else:
+            os.environ["MTR_STAGED"] = staged_before     # the caller's choice for the timed steps stays
     sync_k2 = []
     lone_mode = None
     for w in range(a.warmup):                           # warm-up steps run one at a time (un-overlapped kernel times)

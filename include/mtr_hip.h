@@ -39,7 +39,7 @@ extern "C" {
 /* Longest read the hot path takes: the reference's buffers hold L + 2r entries with r = L/10 random flank bases
  * (handle_one_read.c:194-204), so beyond L + 2r = MAX_INPUT_LENGTH it writes out of bounds; uploads refuse such reads. */
 #define MTR_MAX_READ_LENGTH 833333
-#define MTR_ABI_VERSION 3
+#define MTR_ABI_VERSION 4
 
 typedef enum {
     MTR_OK = 0,
@@ -103,21 +103,6 @@ mtr_status mtr_run_resident_async(mtr_ctx *ctx);
 mtr_status mtr_wait(mtr_ctx *ctx);
 mtr_status mtr_fetch_results(mtr_ctx *ctx, mtr_record **out_records, int32_t **out_counts, int64_t *out_total);
 
-/* ---- one read's candidate ranges spread over several contexts (a long read over the GPUs of a node) ---------------------
- * What the reference does for a candidate range (find_tandem_repeat, handle_one_read.c:235: k-mer tables, walks, alignments,
- * revision, the comparison over k) depends on nothing but the read and the range; only its loop over the ranges is sequential -
- * an accepted repeat removes the later ranges that lie inside it (:178-188, :242-243).  N contexts that hold the SAME batch
- * (the same mtr_upload_batch* call on each) can therefore share the ranges:
- *   mtr_run_ranges_share(ctx, share, n_shares)  searches the ranges t of every read with t % n_shares == share (t = the range's
- *       index among the read's candidate ranges, which every context finds identically) and parks their candidate records;
- *   mtr_export_candidates(ctx, &blob, &bytes)   hands them out (memory owned by the context, valid until its next call);
- *   mtr_replay_candidates(ctx, blobs, bytes, n) on ONE of the contexts, with the blobs of ALL shares (its own may be among them):
- *       replays the reference's loop over every read's ranges; mtr_fetch_results* then give the records of mtr_run_resident.
- * A share run that fails with MTR_ERR_DP_TOO_LARGE or MTR_ERR_OVERFLOW leaves the batch resident: mtr_run_resident on one
- * context gives the reference's behaviour for it.  Not available in the file-order mode. */
-mtr_status mtr_run_ranges_share(mtr_ctx *ctx, int32_t share, int32_t n_shares);
-mtr_status mtr_export_candidates(mtr_ctx *ctx, const uint8_t **out_blob, int64_t *out_bytes);
-mtr_status mtr_replay_candidates(mtr_ctx *ctx, const uint8_t *const *blobs, const int64_t *bytes, int32_t n_blobs);
 /* A failed run (mtr_wait returned an error) is remembered: fetch / export / alignments of that batch return the same
  * status instead of partial records.  After MTR_ERR_DP_TOO_LARGE the reads BEFORE the failing one (input order) are
  * still valid — the reference has printed them when it exits (wrap_around_DP.c:96-99) — and can be fetched with
@@ -200,11 +185,6 @@ mtr_status mtr_file_state_skip(mtr_file_state *fs, const uint8_t *bases, const i
  * the bases an earlier, longer read left there.  A repeat can end on them (wrap_around_DP.c:243-245), and a printer of
  * the -a alignments (mtr_alignments) needs them for its top row. */
 mtr_status mtr_get_bases_after_read(const mtr_ctx *ctx, int32_t read_idx, uint8_t out[2]);
-
-/* Multi-GPU plumbing: compacts the records of the last run (read after read, insertion order) into
- * caller-owned DEVICE memory on the context's GPU (capacity in records) so that the caller can hand it
- * to RCCL without a host round trip; counts_host receives n_reads per-read counts. */
-mtr_status mtr_export_records_device(mtr_ctx *ctx, void *d_dst, int64_t capacity_records, int32_t *counts_host, int64_t *out_total);
 
 /* The -a alignments (replaces pretty_print_alignment, wrap_around_DP.c:57-213, for the repeats the caller chose to
  * report, i.e. after chaining): for n records of reads of the RESIDENT batch (mtr_process_batch / mtr_upload_batch

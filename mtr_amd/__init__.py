@@ -28,12 +28,11 @@ COUNTER_NAMES = ["dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_d
                  "walk_calls", "walk_closed", "cyc_walk_fast", "spare43", "spare44", "spare45", "spare46", "spare47"]
 EXPORTS = ["mtr_create", "mtr_destroy", "mtr_last_error", "mtr_abi_version", "mtr_process_batch", "mtr_free_results",
            "mtr_upload_batch", "mtr_run_resident", "mtr_fetch_results", "mtr_get_kernel_times", "mtr_get_counters",
-           "mtr_test_ranges", "mtr_test_wrap_dp", "mtr_test_last_mode", "mtr_set_trace", "mtr_get_trace", "mtr_export_records_device",
+           "mtr_test_ranges", "mtr_test_wrap_dp", "mtr_test_last_mode", "mtr_set_trace", "mtr_get_trace",
            "mtr_run_resident_async", "mtr_wait", "mtr_alignments",
            "mtr_file_state_create", "mtr_file_state_destroy", "mtr_upload_batch_in_file", "mtr_file_state_skip",
            "mtr_get_bases_after_read", "mtr_upload_batch_packed", "mtr_fetch_results_packed", "mtr_export_packed_device",
-           "mtr_unpack_records", "mtr_pack_records", "mtr_get_first_failed_read",
-           "mtr_run_ranges_share", "mtr_export_candidates", "mtr_replay_candidates"]
+           "mtr_unpack_records", "mtr_pack_records", "mtr_get_first_failed_read"]
 
 
 class MtrError(RuntimeError):
@@ -139,12 +138,6 @@ def load_library(path: str = LIB_PATH):
     lib.mtr_run_resident_async.restype = C.c_int
     lib.mtr_wait.argtypes = [C.c_void_p]
     lib.mtr_wait.restype = C.c_int
-    lib.mtr_run_ranges_share.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
-    lib.mtr_run_ranges_share.restype = C.c_int
-    lib.mtr_export_candidates.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_int64)]
-    lib.mtr_export_candidates.restype = C.c_int
-    lib.mtr_replay_candidates.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_int64), C.c_int32]
-    lib.mtr_replay_candidates.restype = C.c_int
     lib.mtr_test_last_mode.argtypes = [C.c_void_p]
     lib.mtr_test_last_mode.restype = C.c_int32
     lib.mtr_fetch_results.argtypes = [C.c_void_p, P(P(CRecord)), P(P(C.c_int32)), P(C.c_int64)]
@@ -159,8 +152,6 @@ def load_library(path: str = LIB_PATH):
     lib.mtr_test_ranges.restype = C.c_int
     lib.mtr_test_wrap_dp.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 9
     lib.mtr_test_wrap_dp.restype = C.c_int
-    lib.mtr_export_records_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, P(C.c_int64)]
-    lib.mtr_export_records_device.restype = C.c_int
     lib.mtr_upload_batch_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]
     lib.mtr_upload_batch_packed.restype = C.c_int
     lib.mtr_fetch_results_packed.argtypes = [C.c_void_p, C.c_int32, P(C.c_void_p), P(C.c_int64), P(C.c_void_p), P(C.c_int64)]
@@ -248,23 +239,6 @@ class Engine:
 
     def wait(self):
         self._check(self.lib.mtr_wait(self.h), "mtr_wait")
-
-    # ---- one read's ranges spread over several contexts (include/mtr_hip.h) ---------------------------------------------------
-    def run_share(self, share: int, n_shares: int):
-        """search the candidate ranges t % n_shares == share of every read of the resident batch (mtr_run_ranges_share)"""
-        self._check(self.lib.mtr_run_ranges_share(self.h, share, n_shares), "mtr_run_ranges_share")
-
-    def export_candidates(self) -> bytes:
-        p, n = C.c_void_p(), C.c_int64()
-        self._check(self.lib.mtr_export_candidates(self.h, C.byref(p), C.byref(n)), "mtr_export_candidates")
-        return C.string_at(p.value, n.value)
-
-    def replay_candidates(self, blobs: Sequence[bytes]):
-        """the reference's loop over every read's ranges with the candidates of ALL shares (mtr_replay_candidates); then fetch()"""
-        keep = [C.create_string_buffer(b, len(b)) for b in blobs]
-        arr = (C.c_void_p * len(blobs))(*[C.cast(k, C.c_void_p) for k in keep])
-        szs = (C.c_int64 * len(blobs))(*[len(b) for b in blobs])
-        self._check(self.lib.mtr_replay_candidates(self.h, arr, szs, len(blobs)), "mtr_replay_candidates")
 
     def last_mode(self) -> str:
         """how the last launch ran (mtr_test_last_mode)"""
@@ -365,14 +339,6 @@ class Engine:
         v = C.c_int32()
         self.lib.mtr_get_first_failed_read(self.h, C.byref(v))
         return int(v.value)
-
-    def export_records_device(self, device_ptr: int, capacity_records: int):
-        """Compacts the last run's records into caller-owned device memory; returns (counts int32[n_reads], total)."""
-        counts = np.zeros(self.n_reads, np.int32)
-        total = C.c_int64()
-        self._check(self.lib.mtr_export_records_device(self.h, C.c_void_p(device_ptr), capacity_records, counts.ctypes.data, C.byref(total)),
-                    "mtr_export_records_device")
-        return counts, int(total.value)
 
     # ---- measurements ------------------------------------------------------------------------------------
     def kernel_times_ms(self):

@@ -41,14 +41,17 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False) -> 
     """libmtr_hip.so (product).  profile=True builds libmtr_hip_prof.so as well: the same kernels with the phase timers
     compiled in (select it with MTR_LIB=.../libmtr_hip_prof.so; tests/dev/gpu_phase.py does)."""
     targets = [(LIB, [])] + ([(LIB_PROF, ["-DMTR_PROFILE"])] if profile else [])
+    running = []
     for lib, extra in targets:
         stale = force or not os.path.exists(lib) or any(os.path.getmtime(os.path.join(CSRC, s)) > os.path.getmtime(lib) for s in SOURCES)
         if not stale:
             continue
         cmd = [hipcc(), *FLAGS, *extra, "-o", lib, os.path.join(CSRC, "mtr_abi.hip")]
-        p = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+        running.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=CSRC)))    # (the two builds side by side)
+    for cmd, p in running:
+        out, err = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError("hipcc failed:\n" + p.stdout + p.stderr)
+            raise RuntimeError("hipcc failed:\n" + out + err)
         if verbose:
             print(" ".join(cmd))
     return LIB

@@ -70,12 +70,7 @@ struct mtr_ctx {
     long long packed_words = 0;
     long long st_last_arena_cap = 0;
     int32_t st_cand_cap = 0;
-    int32_t share = 0, n_shares = 1;   // mtr_run_ranges_share: this context searches the ranges t % n_shares == share of every read
     int st_last_nsub = 1;              // sub-lists of the chain's last launch (the arena's cursors are read after an overflow)
-    bool skip_replay = false;          // mtr_run_ranges_share: the chain stops before mtr_k_replay
-    bool cand_ready = false;           // a share run has left its candidate records on the device (mtr_export_candidates / mtr_replay_candidates)
-    int64_t st_n_items = 0;            // candidate ranges of the resident batch (work items of the chain)
-    std::vector<uint8_t> cand_blob;
     int64_t st_arena_per_base = 256;   // bytes of candidate arena per read base reserved by the staged chain (x 4 after an overflow)
     uint32_t *d_packed = nullptr; int64_t *d_woff = nullptr; int32_t *d_lens = nullptr, *d_order = nullptr;
     int64_t *d_roff = nullptr; int32_t *d_rcount = nullptr, *d_rstart = nullptr, *d_rend = nullptr, *d_rw = nullptr; uint64_t *d_rdi = nullptr;
@@ -717,7 +712,6 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     ST_ALLOC(ensure_dev(ctx, ctx->d_st_scalars, st_scalar_bytes));
     ST_ALLOC(ensure_dev(ctx, ctx->d_st_wv, (size_t)ST_NCLS * (size_t)s.dp_cap * 4)); ST_ALLOC(ensure_dev(ctx, ctx->d_st_res, (size_t)s.dp_cap * 16 * 4));
     s.quad_min = staged_quad_min(sumL); s.wv_items = ctx->d_st_wv; s.dp_res = ctx->d_st_res;
-    s.share = ctx->share; s.n_shares = ctx->n_shares;
     s.item_cap = (int32_t)std::min<int64_t>(0x7fffff00, ctx->total_rcap);
     ST_ALLOC(ensure_dev(ctx, ctx->d_st_items, (size_t)std::max(s.item_cap, 1) * sizeof(int4)));
     s.item_tab = ctx->d_st_items;
@@ -800,7 +794,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     if (s.quad_min > 0) {
         hipLaunchKernelGGL(mtr_k_qbins, dim3(1), dim3(1024), 0, ctx->stream, s, 0);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(mtr_k_qscatter, dim3((unsigned)capped(512, 16384)), dim3(256), 0, ctx->stream, s);
+        hipLaunchKernelGGL(mtr_k_qscatter, dim3((unsigned)capped(512, 16384)), dim3(256), 0, ctx->stream, s, ctx->d_status);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(mtr_k_dp2_quads, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
         HIPCHK(hipGetLastError());
@@ -827,12 +821,10 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     hipLaunchKernelGGL(mtr_k_finish, dim3((unsigned)capped(ctx->n_cu * 32, 64)), dim3(64), 0, ctx->stream, a, s);
     HIPCHK(hipGetLastError());
     ctx->st_cand_cap = s.cand_cap;
-    if (!ctx->skip_replay) {                                // (a share run stops here: the replay needs every rank's candidates)
-        SplitArgs sp{};
-        sp.item_off = ctx->d_item_off; sp.cand = ctx->d_st_cand; sp.cand_flag = ctx->d_st_flag;
-        hipLaunchKernelGGL(mtr_k_replay, dim3((unsigned)std::min(n, 65535)), dim3(64), 0, ctx->stream, a, sp);
-        HIPCHK(hipGetLastError());
-    }
+    SplitArgs sp{};
+    sp.item_off = ctx->d_item_off; sp.cand = ctx->d_st_cand; sp.cand_flag = ctx->d_st_flag;
+    hipLaunchKernelGGL(mtr_k_replay, dim3((unsigned)std::min(n, 65535)), dim3(64), 0, ctx->stream, a, sp);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
     return MTR_OK;
 }
@@ -880,115 +872,6 @@ extern "C" mtr_status mtr_run_resident_async(mtr_ctx *ctx)
     mtr_status s = ctx->last_staged ? launch_staged(ctx) : launch_reads(ctx); if (s != MTR_OK) return s;
     ctx->pending = true;
     return MTR_OK;
-}
-
-// ---- one read's ranges spread over several contexts / ranks (include/mtr_hip.h) --------------------------------------------------
-// A candidate range's search (tables, walks, alignments, revision, comparison over k) depends on nothing but the read and the
-// range; only the replay of the reference's sequential loop (handle_one_read.c:227-246: an accepted repeat removes the later
-// ranges inside it) needs them all.  So N contexts that hold the SAME batch each search the ranges t % N == share, their
-// candidate records are brought together (mtr_export_candidates -> the caller's exchange -> mtr_replay_candidates on one of
-// them), and that one replays the loop: the records are those of mtr_run_resident.
-static const int64_t CAND_MAGIC = 0x4d54524341444e31ll;      // "MTRCADN1"
-extern "C" mtr_status mtr_run_ranges_share(mtr_ctx *ctx, int32_t share, int32_t n_shares)
-{
-    if (!ctx) return MTR_ERR_BAD_ARG;
-    if (ctx->n_reads <= 0) { ctx->err = "no batch uploaded"; return MTR_ERR_BAD_ARG; }
-    if (n_shares < 1 || share < 0 || share >= n_shares) { ctx->err = "share must be in [0, n_shares)"; return MTR_ERR_BAD_ARG; }
-    if (ctx->file_order) { ctx->err = "the file-order mode does not split a read's ranges"; return MTR_ERR_BAD_ARG; }
-    HIPCHK(hipSetDevice(ctx->device));
-    { mtr_status w = mtr_wait(ctx); if (w != MTR_OK && ctx->pending) return w; }
-    ctx->cand_ready = false;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        ctx->run_status = MTR_OK; ctx->ran = false; ctx->first_failed = -1; ctx->ovf_reads.clear();
-        HIPCHK(hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->d_fail_read, 0x7f, 4, ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
-        ctx->share = share; ctx->n_shares = n_shares; ctx->skip_replay = true;
-        ctx->last_staged = true;
-        const mtr_status s = launch_staged(ctx);
-        ctx->share = 0; ctx->n_shares = 1; ctx->skip_replay = false;
-        if (s != MTR_OK) return s;
-        if (!ctx->last_staged) { ctx->err = "the chain's buffers could not be allocated"; HIPCHK(hipStreamSynchronize(ctx->stream)); return MTR_ERR_OVERFLOW; }
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        const mtr_status st = check_status(ctx);
-        if (st == MTR_OK) break;
-        int32_t dst = 0;
-        HIPCHK(copy_sync(ctx, &dst, ctx->d_status, 4, hipMemcpyDeviceToHost));
-        if (dst == DEV_ERR_STAGED_OVERFLOW && attempt == 0 && ctx->st_arena_per_base < 1024) { ctx->st_arena_per_base *= 4; continue; }
-        return st;                                          // (MTR_ERR_DP_TOO_LARGE: the caller runs the read whole, where the reference's own loop decides)
-    }
-    HIPCHK(copy_sync(ctx, ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));
-    ctx->cand_ready = true;
-    return MTR_OK;
-}
-
-extern "C" mtr_status mtr_export_candidates(mtr_ctx *ctx, const uint8_t **out_blob, int64_t *out_bytes)
-{
-    if (!ctx || !out_blob || !out_bytes) return MTR_ERR_BAD_ARG;
-    if (!ctx->cand_ready) { ctx->err = "no share run to export (mtr_run_ranges_share)"; return MTR_ERR_BAD_ARG; }
-    HIPCHK(hipSetDevice(ctx->device));
-    unsigned long long sc[6 * 32];
-    HIPCHK(copy_sync(ctx, sc, ctx->d_st_scalars, sizeof sc, hipMemcpyDeviceToHost));
-    const int64_t n_items = (int32_t)sc[0];
-    int64_t n_cand = (int64_t)(unsigned)sc[5 * 32];
-    if (n_cand > ctx->st_cand_cap) n_cand = ctx->st_cand_cap;
-    std::vector<int32_t> flag((size_t)std::max<int64_t>(n_items, 1));
-    if (n_items > 0) HIPCHK(copy_sync(ctx, flag.data(), ctx->d_st_flag, (size_t)n_items * 4, hipMemcpyDeviceToHost));
-    // header: magic, items of the batch, candidates; then per candidate its item index (8 bytes) and its record
-    ctx->cand_blob.assign((size_t)(24 + n_cand * (8 + (int64_t)sizeof(DevRecord))), 0);
-    int64_t *h = (int64_t *)ctx->cand_blob.data();
-    h[0] = CAND_MAGIC; h[1] = n_items; h[2] = n_cand;
-    uint8_t *p = ctx->cand_blob.data() + 24;
-    std::vector<int64_t> item_of((size_t)std::max<int64_t>(n_cand, 1), -1);
-    for (int64_t it = 0; it < n_items; it++) { const int32_t f = flag[(size_t)it]; if (f > 0 && f <= n_cand) item_of[(size_t)(f - 1)] = it; }
-    if (n_cand > 0) {
-        std::vector<DevRecord> recs((size_t)n_cand);
-        HIPCHK(copy_sync(ctx, recs.data(), ctx->d_st_cand, (size_t)n_cand * sizeof(DevRecord), hipMemcpyDeviceToHost));
-        for (int64_t c = 0; c < n_cand; c++) { memcpy(p, &item_of[(size_t)c], 8); memcpy(p + 8, &recs[(size_t)c], sizeof(DevRecord)); p += 8 + sizeof(DevRecord); }
-    }
-    ctx->st_n_items = n_items;
-    *out_blob = ctx->cand_blob.data(); *out_bytes = (int64_t)ctx->cand_blob.size();
-    return MTR_OK;
-}
-
-extern "C" mtr_status mtr_replay_candidates(mtr_ctx *ctx, const uint8_t *const *blobs, const int64_t *bytes, int32_t n_blobs)
-{
-    if (!ctx || (n_blobs > 0 && (!blobs || !bytes))) return MTR_ERR_BAD_ARG;
-    if (!ctx->cand_ready) { ctx->err = "mtr_replay_candidates needs this context's own share run first (it holds the batch's ranges)"; return MTR_ERR_BAD_ARG; }
-    HIPCHK(hipSetDevice(ctx->device));
-    unsigned long long sc[6 * 32];
-    HIPCHK(copy_sync(ctx, sc, ctx->d_st_scalars, sizeof sc, hipMemcpyDeviceToHost));
-    const int64_t n_items = (int32_t)sc[0];
-    int64_t n_cand = (int64_t)(unsigned)sc[5 * 32];
-    std::vector<int32_t> flag((size_t)std::max<int64_t>(n_items, 1));
-    if (n_items > 0) HIPCHK(copy_sync(ctx, flag.data(), ctx->d_st_flag, (size_t)n_items * 4, hipMemcpyDeviceToHost));
-    std::vector<DevRecord> add;
-    for (int b = 0; b < n_blobs; b++) {
-        if (bytes[b] < 24 || !blobs[b]) { ctx->err = "malformed candidate blob"; return MTR_ERR_BAD_ARG; }
-        int64_t h[3]; memcpy(h, blobs[b], 24);
-        if (h[0] != CAND_MAGIC || h[1] != n_items || h[2] < 0 || bytes[b] != 24 + h[2] * (8 + (int64_t)sizeof(DevRecord))) { ctx->err = "candidate blob of another batch"; return MTR_ERR_BAD_ARG; }
-        const uint8_t *p = blobs[b] + 24;
-        for (int64_t c = 0; c < h[2]; c++, p += 8 + sizeof(DevRecord)) {
-            int64_t it; memcpy(&it, p, 8);
-            if (it < 0 || it >= n_items) { ctx->err = "candidate of a range the batch does not have"; return MTR_ERR_BAD_ARG; }
-            if (flag[(size_t)it] > 0) continue;           // (this context's own share, handed back by the caller's gather)
-            DevRecord r; memcpy(&r, p + 8, sizeof r);
-            add.push_back(r);
-            flag[(size_t)it] = (int32_t)(n_cand + (int64_t)add.size());
-        }
-    }
-    if (n_cand + (int64_t)add.size() > ctx->st_cand_cap) { ctx->err = "more candidate records than the chain's capacity"; return MTR_ERR_OVERFLOW; }
-    if (!add.empty()) HIPCHK(copy_sync(ctx, ctx->d_st_cand + n_cand, add.data(), add.size() * sizeof(DevRecord), hipMemcpyHostToDevice));
-    if (n_items > 0) HIPCHK(copy_sync(ctx, ctx->d_st_flag, flag.data(), (size_t)n_items * 4, hipMemcpyHostToDevice));
-    K2Args a{}; k2_args(ctx, a, 0);
-    SplitArgs sp{};
-    sp.item_off = ctx->d_item_off; sp.cand = ctx->d_st_cand; sp.cand_flag = ctx->d_st_flag;
-    hipLaunchKernelGGL(mtr_k_replay, dim3((unsigned)std::min(ctx->n_reads, 65535)), dim3(64), 0, ctx->stream, a, sp);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
-    ctx->cand_ready = false;
-    ctx->last_staged = true; ctx->pending = true;
-    return mtr_wait(ctx);                                  // status, counters, reads with more records than slots: as after mtr_run_resident
 }
 
 extern "C" int32_t mtr_test_last_mode(const mtr_ctx *ctx) { return !ctx ? -1 : ctx->last_staged ? 2 : 0; }
@@ -1333,30 +1216,6 @@ extern "C" int64_t mtr_pack_records(const mtr_record *records, int64_t n_records
         o += need;
     }
     return o;
-}
-
-// Multi-GPU plumbing: compact the records of the last run into caller-owned DEVICE memory (e.g. a torch
-// uint8 tensor that RCCL then gathers to rank 0); counts go to host.
-extern "C" mtr_status mtr_export_records_device(mtr_ctx *ctx, void *d_dst, int64_t capacity_records, int32_t *counts_host, int64_t *out_total)
-{
-    if (!ctx || !counts_host || !out_total) return MTR_ERR_BAD_ARG;
-    { mtr_status r = results_ready(ctx, false); if (r != MTR_OK) return r; }
-    HIPCHK(hipSetDevice(ctx->device));
-    const int n = ctx->n_reads;
-    HIPCHK(copy_sync(ctx, counts_host, ctx->d_reccount, (size_t)n * 4, hipMemcpyDeviceToHost));
-    std::vector<int64_t> off((size_t)n + 1, 0);
-    for (int i = 0; i < n; i++) off[(size_t)i + 1] = off[(size_t)i] + counts_host[i];
-    *out_total = off[(size_t)n];
-    if (off[(size_t)n] == 0) return MTR_OK;
-    if (!d_dst || off[(size_t)n] > capacity_records) { ctx->err = "destination holds " + std::to_string(capacity_records) + " records, " + std::to_string(off[(size_t)n]) + " needed"; return MTR_ERR_OVERFLOW; }
-    int64_t *d_off = ctx->d_recoff;
-    HIPCHK(hipMemcpyAsync(d_off, off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    const DevRecord *const *srcs = nullptr;
-    { mtr_status st = record_sources(ctx, &srcs); if (st != MTR_OK) return st; }
-    hipLaunchKernelGGL(mtr_k_compact, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->d_records, srcs, ctx->d_reccount, d_off, ctx->max_rec, n, (DevRecord *)d_dst);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return MTR_OK;
 }
 
 extern "C" mtr_status mtr_process_batch(mtr_ctx *ctx, const uint8_t *bases, const int64_t *offsets, const int32_t *lens,

@@ -45,10 +45,6 @@ int mtrh_engine_load(mtrh_engine *e, const char *lib_path, char *err, size_t err
     BIND(first_failed, "mtr_get_first_failed_read"); BIND(alignments, "mtr_alignments"); BIND(bases_after, "mtr_get_bases_after_read");
     BIND(kernel_times, "mtr_get_kernel_times"); BIND(counters, "mtr_get_counters");
     BIND(fs_create, "mtr_file_state_create"); BIND(fs_destroy, "mtr_file_state_destroy"); BIND(fs_skip, "mtr_file_state_skip");
-    *(void **)(&e->run_share) = dlsym(e->dl, "mtr_run_ranges_share");
-    *(void **)(&e->export_cand) = dlsym(e->dl, "mtr_export_candidates");
-    *(void **)(&e->replay_cand) = dlsym(e->dl, "mtr_replay_candidates");
-    if (!e->run_share || !e->export_cand || !e->replay_cand) { e->run_share = NULL; e->export_cand = NULL; e->replay_cand = NULL; }
     __typeof__(mtr_abi_version) *ver = NULL;
     *(void **)(&ver) = dlsym(e->dl, "mtr_abi_version");
     if (!ver || ver() != MTR_ABI_VERSION) {

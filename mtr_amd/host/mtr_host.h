@@ -60,9 +60,6 @@ typedef struct mtrh_engine {
     __typeof__(mtr_file_state_create) *fs_create;
     __typeof__(mtr_file_state_destroy) *fs_destroy;
     __typeof__(mtr_file_state_skip) *fs_skip;
-    __typeof__(mtr_run_ranges_share) *run_share;        /* optional (NULL: the library cannot spread a read's ranges): the three come together */
-    __typeof__(mtr_export_candidates) *export_cand;
-    __typeof__(mtr_replay_candidates) *replay_cand;
     char path[4096];                    /* the library that was bound, resolved (reported by mTR -c) */
 } mtrh_engine;
 /* dlopen a library that implements include/mtr_hip.h; lib_path NULL = $MTR_LIB, else libmtr_hip.so next to this code */
@@ -135,7 +132,6 @@ typedef struct mtrh_opts {
     size_t chunk_bytes;                    /* 0 = default */
     int   parse_threads, print_threads;    /* 0 = default */
     const char *engine_lib;                /* NULL = default (mtrh_engine_load) */
-    size_t split_bytes;                    /* lpt: a file of at least this many bytes may be spread over several ranks (0 or (size_t)-1 = never, the default) */
 } mtrh_opts;
 typedef struct mtrh_run mtrh_run;
 /* opens the files, plans the chunks, starts the parser threads and the device thread; NULL + message on stderr on failure */
@@ -153,14 +149,6 @@ void  mtrh_stamp(const char *what);           /* development aid: with MTR_HOST_
 void  mtrh_run_stop(mtrh_run *r);
 /* all results this rank produces for `round`, serialised one after the other (malloc'ed; free() it) */
 uint8_t *mtrh_run_round_blob(mtrh_run *r, int round, size_t *bytes);
-/* A long read spread over ranks (several files, mtrh_opts.split_bytes): every rank of the read's group searches its share of the
- * read's candidate ranges (mtr_run_ranges_share); the candidate records travel in round 0 - mtrh_run_round_blob(r, 0) - which the
- * launcher ALL-gathers and hands back to every rank with mtrh_run_feed; the group's first rank replays the reference's loop over the
- * ranges and produces the read's result, which travels with the others in round 1.  mtrh_run_has_split: round 0 is that exchange. */
-int   mtrh_run_has_split(const mtrh_run *r);
-int   mtrh_run_n_shares(const mtrh_run *r, int chunk);          /* ranks that share the chunk's read(s) (1 = not split) */
-int   mtrh_run_share_rank(const mtrh_run *r, int chunk, int s); /* the rank that searches share s (share 0 also reports the chunk) */
-void  mtrh_run_feed(mtrh_run *r, const uint8_t *const *blobs, const size_t *sizes, int n_blobs);
 
 /* ---- printing: chaining.cpp:125-171 (+ the alignment block of wrap_around_DP.c:187-212 with -a) --------------------- */
 typedef struct mtrh_printer mtrh_printer;

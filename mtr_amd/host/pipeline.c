@@ -21,19 +21,13 @@
 #define PARSE_AHEAD 3
 #define RESULT_QUEUE 4
 
-#define MAX_SHARES 16
-/* Part of a long read's time that every rank of its group spends whatever its share: the candidate ranges (one read = one chain of
- * passes) AND the critical path of the per-range kernels, which one read cannot fill the GPU with anyway.  Measured on MI355X
- * (profiles/r03_share_cost.json): a 140 kb read 47.4 ms whole, 41.4 / 41.0 / 40.7 ms as one of 2 / 4 / 8 shares.  Sharing a read
- * therefore only pays where ranks would otherwise idle, and is opt-in (mtrh_opts.split_bytes, --split-bytes). */
-#define RANGE_PHASE_SHARE 0.85
-typedef struct { int file; size_t begin, end; int owner, round; int n_shares; int shares[MAX_SHARES]; } chunk_t;   /* shares[0] == owner: replays and reports */
+typedef struct { int file; size_t begin, end; int owner, round; } chunk_t;
 
 struct mtrh_run {
     mtrh_opts o; mtrh_engine eng;
     int n_files; mtrh_file *files;
     int n_chunks, n_rounds; chunk_t *chunks;
-    int n_list; int *list;                     /* the chunks this rank parses: those it shares with other ranks, then ascending its own (with -B also those before them) */
+    int n_list; int *list;                     /* the chunks this rank parses, ascending: its own (with -B also those before them) */
     mtrh_batch **parsed; int *pstate;          /* per list entry */
     int next_parse, consumed;
     pthread_mutex_t mu; pthread_cond_t cv_parse, cv_res;
@@ -41,12 +35,8 @@ struct mtrh_run {
     mtrh_result *queue[RESULT_QUEUE]; int q_head, q_n, device_done, stopping;
     double t_parse_wait, t_submit, t_fetch, t_kernel; long long queries;
     int overlap;                                   /* more than one device batch: launches of the two contexts overlap */
-    /* long reads spread over ranks (lpt) */
     int parse_failed;                              /* a parser thread could not allocate: the device thread reports it */
     int *chunk_done;                               /* per chunk: its last result has been handed on */
-    int has_split;
-    uint8_t *cand_out; size_t cand_out_bytes; int cand_out_ready;       /* round 0: this rank's candidate records, [chunk, share, bytes | -1][blob] ... */
-    uint8_t **fed; size_t *fed_bytes; int n_fed, fed_ready;             /* what the launcher all-gathered and handed back */
 };
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
@@ -84,9 +74,8 @@ static void plan(mtrh_run *r)
         for (int c = 0; c < nc; c++) { chunk_t *k = &r->chunks[r->n_chunks++]; k->file = f; k->begin = off[c]; k->end = off[c + 1]; }
         free(off);
     }
-    for (int c = 0; c < r->n_chunks; c++) r->chunks[c].n_shares = 1;
     if (!r->o.lpt) {
-        for (int c = 0; c < r->n_chunks; c++) { r->chunks[c].owner = c % world; r->chunks[c].shares[0] = c % world; r->chunks[c].round = c / world; }
+        for (int c = 0; c < r->n_chunks; c++) { r->chunks[c].owner = c % world; r->chunks[c].round = c / world; }
         r->n_rounds = (r->n_chunks + world - 1) / world;
     } else {
         /* longest processing time first: a read's cost grows faster than its length (the DPs of a range are rows x unit) */
@@ -94,37 +83,14 @@ static void plan(mtrh_run *r)
         double *load = (double *)calloc((size_t)world, sizeof(double));
         for (int c = 0; c < r->n_chunks; c++) ord[c] = &r->chunks[c];
         qsort(ord, (size_t)r->n_chunks, sizeof(chunk_t *), cmp_size_desc);
-        /* On request a file whose cost exceeds what a rank should get is spread over g ranks: each repeats the candidate ranges
-         * and searches 1/g of them (mtr_run_ranges_share).  g = what brings a share down to the target, if anything does. */
-        const size_t split_bytes = r->o.split_bytes;
-        const int can_split = world > 1 && r->eng.run_share && !r->o.file_order && split_bytes != 0 && split_bytes != (size_t)-1;
-        double total = 0;
-        for (int c = 0; c < r->n_chunks; c++) total += pow((double)(r->chunks[c].end - r->chunks[c].begin), 1.5);
-        const double target = total / world;
         for (int c = 0; c < r->n_chunks; c++) {
             chunk_t *k = ord[c];
-            const double cost = pow((double)(k->end - k->begin), 1.5);
-            int g = 1;
-            if (can_split && k->end - k->begin >= split_bytes && cost > 0.9 * target) {
-                g = (int)ceil((1.0 - RANGE_PHASE_SHARE) * cost / fmax(0.9 * target - RANGE_PHASE_SHARE * cost, 0.05 * cost));
-                if (g < 2) g = 2;
-                if (g > world) g = world;
-                if (g > MAX_SHARES) g = MAX_SHARES;
-            }
-            k->n_shares = g; k->round = 0;
-            char taken[256]; memset(taken, 0, sizeof taken);
-            for (int s = 0; s < g; s++) {
-                int best = -1;
-                for (int q = 0; q < world; q++) if (!taken[q & 255] && (best < 0 || load[q] < load[best])) best = q;
-                taken[best & 255] = 1;
-                k->shares[s] = best;
-                load[best] += g == 1 ? cost : RANGE_PHASE_SHARE * cost + (1.0 - RANGE_PHASE_SHARE) * cost / g;
-            }
-            k->owner = k->shares[0];
-            if (g > 1) r->has_split = 1;
+            int best = 0;
+            for (int q = 1; q < world; q++) if (load[q] < load[best]) best = q;
+            k->owner = best; k->round = 0;
+            load[best] += pow((double)(k->end - k->begin), 1.5);
         }
-        if (r->has_split) for (int c = 0; c < r->n_chunks; c++) r->chunks[c].round = 1;      /* round 0 carries the candidate records */
-        r->n_rounds = r->n_chunks > 0 ? (r->has_split ? 2 : 1) : 0;
+        r->n_rounds = r->n_chunks > 0 ? 1 : 0;
         free(ord); free(load);
     }
 }
@@ -292,21 +258,6 @@ static void finish_batch(mtrh_run *r, mtr_ctx *ctx, mtrh_result *x)
     push_result(r, x);
 }
 
-static int share_of(const chunk_t *c, int rank)
-{
-    for (int s = 0; s < c->n_shares; s++) if (c->shares[s] == rank) return s;
-    return -1;
-}
-
-static void blob_append(uint8_t **out, size_t *n, size_t *cap, const void *src, size_t bytes)
-{
-    if (*n + bytes > *cap) { size_t c = *cap ? *cap * 2 : 1 << 16; while (c < *n + bytes) c *= 2; *out = (uint8_t *)realloc(*out, c); if (!*out) { fprintf(stderr, "cannot allocate the candidate round\n"); exit(EXIT_FAILURE); } *cap = c; }
-    memcpy(*out + *n, src, bytes); *n += bytes;
-}
-
-/* what a rank keeps of a read it shares and will report (it holds share 0) between the two halves */
-typedef struct { int list_idx; mtr_ctx *ctx; mtrh_batch *batch; int ok; } split_job;
-
 /* after a failed allocation (this thread's or a parser's): every chunk this rank reports and has not finished gets a result that
  * carries the message - what is printed before it stays printed, the run ends with status 1, and no rank waits for a chunk forever */
 static void report_failure(mtrh_run *r, const char *msg)
@@ -326,18 +277,27 @@ static void report_failure(mtrh_run *r, const char *msg)
     }
 }
 
-static void device_body(mtrh_run *r);
+/* what the device thread holds while it runs: kept outside device_body so that a failed allocation (a longjmp out of it) still
+ * finds the batch in flight and the contexts - they are waited for and destroyed, not left to the process's end */
+typedef struct { mtr_ctx *ctxs[2]; mtr_file_state *fs; mtrh_result *prev; mtr_ctx *prev_ctx; int *file_ended; char *dead_msg; } device_state;
+static void device_body(mtrh_run *r, device_state *d);
 static void *device_main(void *arg)
 {
     mtrh_run *r = (mtrh_run *)arg;
     jmp_buf oom;
+    device_state d; memset(&d, 0, sizeof d);
     mtrh_thread_kind = MTRH_THREAD_DEVICE;
     if (setjmp(oom)) {                                   /* an allocation of this thread failed (alloc.c) */
         mtrh_oom_target = NULL;
+        if (d.prev && d.prev_ctx) (void)r->eng.wait(d.prev_ctx);
+        mtrh_result_free(d.prev);
+        if (d.fs) r->eng.fs_destroy(d.fs);
+        for (int t = 0; t < 2; t++) if (d.ctxs[t]) { (void)r->eng.wait(d.ctxs[t]); r->eng.destroy(d.ctxs[t]); }
+        free(d.file_ended); free(d.dead_msg);
         report_failure(r, "fatal error: cannot allocate memory");
     } else {
         mtrh_oom_target = &oom;
-        device_body(r);
+        device_body(r, &d);
         mtrh_oom_target = NULL;
     }
     pthread_mutex_lock(&r->mu);
@@ -347,69 +307,19 @@ static void *device_main(void *arg)
     return NULL;
 }
 
-static void device_body(mtrh_run *r)
+#define ctxs (d->ctxs)
+#define fs (d->fs)
+#define prev (d->prev)
+#define prev_ctx (d->prev_ctx)
+#define file_ended (d->file_ended)
+#define dead_msg (d->dead_msg)
+static void device_body(mtrh_run *r, device_state *d)
 {
     /* Two contexts = two device batches in flight.  The second one is created when a second batch shows up. */
-    mtr_ctx *ctxs[2] = { NULL, NULL };
-    mtr_file_state *fs = NULL;
     int fs_file = -1;
-    mtrh_result *prev = NULL; mtr_ctx *prev_ctx = NULL;
     int k = 0, dead = 0;
-    char *dead_msg = NULL;
-    int *file_ended = (int *)calloc((size_t)r->n_files + 1, sizeof(int));
-    /* ---- the reads this rank shares with others: its share of their candidate ranges first, so that the candidate records can travel
-     * (round 0) while the rank's own files run */
-    split_job *jobs = NULL; int n_jobs = 0;
-    if (r->has_split) {
-        uint8_t *out = NULL; size_t on = 0, ocap = 0;
-        jobs = (split_job *)calloc((size_t)r->n_list + 1, sizeof(split_job));
-        for (int idx = 0; idx < r->n_list; idx++) {
-            const int cid = r->list[idx];
-            const chunk_t *c = &r->chunks[cid];
-            if (c->n_shares <= 1) continue;
-            const int share = share_of(c, r->o.rank);
-            pthread_mutex_lock(&r->mu);
-            while (!r->pstate[idx] && !r->stopping && !r->parse_failed) pthread_cond_wait(&r->cv_parse, &r->mu);
-            if (!r->pstate[idx] && r->parse_failed && !r->stopping) { pthread_mutex_unlock(&r->mu); mtrh_oom(0); }     /* (reported like this thread's own failure) */
-            mtrh_batch *b = r->parsed[idx];
-            r->parsed[idx] = NULL;                              /* (the reporting rank keeps the batch in its job for the second half) */
-            r->consumed = idx + 1;
-            pthread_cond_broadcast(&r->cv_parse);
-            const int stopping = r->stopping;
-            pthread_mutex_unlock(&r->mu);
-            if (stopping) { mtrh_batch_free(b); break; }
-            int64_t hdr[3] = { cid, share, -1 };
-            /* only a file that is ONE batch of reads without an input error is shared; everything else the reporting rank runs whole
-             * (every rank of the group sees the same parse and decides the same) */
-            const int plain = b && !b->next && b->n > 0 && b->end == MTRH_END_NONE && !dead;
-            mtr_ctx *ctx = NULL;
-            if (plain) {
-                mtr_ctx **pc = share == 0 ? &ctx : &ctxs[0];
-                if (!*pc && r->eng.create(r->o.device, r->o.manhattan, r->o.min_match_ratio, pc) != MTR_OK) *pc = NULL;
-                if (*pc && r->eng.upload_packed(*pc, b->packed, b->n_words, b->woff, b->lens, b->n) == MTR_OK
-                        && r->eng.run_share(*pc, share, c->n_shares) == MTR_OK) {
-                    const uint8_t *blob = NULL; int64_t bytes = 0;
-                    if (share == 0) hdr[2] = 0;                 /* (its candidates stay on its device) */
-                    else if (r->eng.export_cand(*pc, &blob, &bytes) == MTR_OK) {
-                        hdr[2] = bytes;
-                        blob_append(&out, &on, &ocap, hdr, sizeof hdr);
-                        blob_append(&out, &on, &ocap, blob, (size_t)bytes);
-                    }
-                }
-                ctx = *pc;
-            }
-            if (hdr[2] <= 0) blob_append(&out, &on, &ocap, hdr, sizeof hdr);      /* (share 0, or a share that could not be searched) */
-            if (share == 0) { jobs[n_jobs].list_idx = idx; jobs[n_jobs].ctx = ctx; jobs[n_jobs].batch = b; jobs[n_jobs].ok = plain && hdr[2] == 0; n_jobs++; }
-            else mtrh_batch_free(b);
-        }
-        pthread_mutex_lock(&r->mu);
-        r->cand_out = out; r->cand_out_bytes = on; r->cand_out_ready = 1;
-        pthread_cond_broadcast(&r->cv_res);
-        pthread_mutex_unlock(&r->mu);
-        mtrh_stamp("shares of the long reads searched");
-    }
+    file_ended = (int *)calloc((size_t)r->n_files + 1, sizeof(int));
     for (int idx = 0; idx < r->n_list; idx++) {
-        if (r->chunks[r->list[idx]].n_shares > 1) continue;            /* (handled above and below) */
         double t0 = now_s();
         pthread_mutex_lock(&r->mu);
         while (!r->pstate[idx] && !r->stopping && !r->parse_failed) pthread_cond_wait(&r->cv_parse, &r->mu);
@@ -491,79 +401,19 @@ static void device_body(mtrh_run *r)
         }
     }
     if (prev) { finish_batch(r, prev_ctx, prev); prev = NULL; }
-    /* ---- the reads this rank reports for its group: the others' candidate records have come back (mtrh_run_feed) */
-    if (n_jobs > 0) {
-        pthread_mutex_lock(&r->mu);
-        while (!r->fed_ready && !r->stopping) pthread_cond_wait(&r->cv_res, &r->mu);
-        const int stopping = r->stopping;
-        pthread_mutex_unlock(&r->mu);
-        for (int j = 0; j < n_jobs; j++) {
-            if (stopping) { mtrh_batch_free(jobs[j].batch); if (jobs[j].ctx) r->eng.destroy(jobs[j].ctx); continue; }
-            const int cid = r->list[jobs[j].list_idx];
-            const chunk_t *c = &r->chunks[cid];
-            mtrh_batch *b = jobs[j].batch;
-            mtr_ctx *ctx = jobs[j].ctx;
-            /* the other shares' blobs: every rank's round-0 string is a sequence of [chunk, share, bytes][blob] */
-            const uint8_t *blobs[MAX_SHARES]; int64_t sizes[MAX_SHARES]; int nb = 0, whole = !jobs[j].ok;
-            int seen[MAX_SHARES]; memset(seen, 0, sizeof seen); seen[0] = 1;
-            for (int k = 0; k < r->n_fed && !whole; k++) {
-                size_t o = 0;
-                while (o + 24 <= r->fed_bytes[k]) {
-                    int64_t hdr[3]; memcpy(hdr, r->fed[k] + o, 24); o += 24;
-                    const size_t len = hdr[2] > 0 ? (size_t)hdr[2] : 0;
-                    if (o + len > r->fed_bytes[k]) { whole = 1; break; }
-                    if (hdr[0] == cid && hdr[1] > 0 && hdr[1] < c->n_shares) {
-                        if (hdr[2] < 0) whole = 1;              /* that share could not be searched (a matrix beyond WrapDPsize, memory) */
-                        else if (nb < MAX_SHARES) { blobs[nb] = r->fed[k] + o; sizes[nb] = hdr[2]; nb++; seen[hdr[1]] = 1; }
-                    }
-                    o += len;
-                }
-            }
-            for (int s = 0; s < c->n_shares; s++) if (!seen[s]) whole = 1;
-            mtrh_batch *bb = b;
-            while (bb) {                                        /* (a shared file is one batch; a file that was not shared after all may be several) */
-                mtrh_batch *nx = bb->next; bb->next = NULL;
-                mtrh_result *x = result_new(cid, c->file, bb);
-                x->last_of_chunk = nx == NULL;
-                mtr_status st = MTR_OK;
-                if (dead || bb->n == 0 || file_ended[c->file]) {
-                    if (dead) { x->n_report = 0; x->counts = (int32_t *)calloc(1, sizeof(int32_t)); result_fail(x, 0, dead_msg); }
-                    else { if (file_ended[c->file]) { x->n_report = 0; bb->end = MTRH_END_NONE; } x->counts = (int32_t *)calloc((size_t)x->n_report + 1, sizeof(int32_t)); if (bb->n == 0) x->n_report = 0; }
-                    if (bb->end != MTRH_END_NONE) file_ended[c->file] = 1;
-                    push_result(r, x);
-                    bb = nx;
-                    continue;
-                }
-                if (!ctx && r->eng.create(r->o.device, r->o.manhattan, r->o.min_match_ratio, &ctx) != MTR_OK) { dead = 1; dead_msg = strdup("fatal error: no usable HIP device"); }
-                if (!dead) {
-                    if (!whole) st = r->eng.replay_cand(ctx, blobs, sizes, nb);
-                    if (!whole && st != MTR_OK && st != MTR_ERR_DP_TOO_LARGE && st != MTR_ERR_OVERFLOW) { dead = 1; dead_msg = strdup(r->eng.last_error(ctx)); }
-                    else if (whole || st == MTR_ERR_OVERFLOW) {
-                        /* the reference's behaviour for a read that could not be shared: the whole read on this rank */
-                        st = r->eng.upload_packed(ctx, bb->packed, bb->n_words, bb->woff, bb->lens, bb->n);
-                        if (st == MTR_OK) st = r->eng.run_async(ctx);
-                        if (st != MTR_OK) { dead = 1; dead_msg = strdup(r->eng.last_error(ctx)); }
-                    }
-                }
-                if (dead) { x->counts = (int32_t *)calloc(1, sizeof(int32_t)); result_fail(x, 0, dead_msg); push_result(r, x); }
-                else {
-                    if (!r->o.print_alignment) { free(bb->codes); bb->codes = NULL; }
-                    free(bb->packed); bb->packed = NULL;
-                    if (bb->end != MTRH_END_NONE) file_ended[c->file] = 1;
-                    finish_batch(r, ctx, x);
-                }
-                bb = nx;
-            }
-            if (ctx) r->eng.destroy(ctx);
-        }
-    }
-    free(jobs);
     mtrh_stamp("last batch fetched");
     if (fs) r->eng.fs_destroy(fs);
     for (int t = 0; t < 2; t++) if (ctxs[t]) r->eng.destroy(ctxs[t]);
     mtrh_stamp("device contexts destroyed");
     free(file_ended); free(dead_msg);
+    memset(d, 0, sizeof *d);
 }
+#undef ctxs
+#undef fs
+#undef prev
+#undef prev_ctx
+#undef file_ended
+#undef dead_msg
 
 /* ---- start / stop ------------------------------------------------------------------------------------------------------- */
 mtrh_run *mtrh_run_start(const mtrh_opts *o, const char *const *paths, int n_paths)
@@ -583,10 +433,8 @@ mtrh_run *mtrh_run_start(const mtrh_opts *o, const char *const *paths, int n_pat
     /* what this rank parses: its own chunks; with -B every chunk up to its last one (the state needs the reads before) */
     r->list = (int *)malloc(sizeof(int) * ((size_t)r->n_chunks + 1));
     int last_owned = -1;
-    for (int c = 0; c < r->n_chunks; c++) if (share_of(&r->chunks[c], r->o.rank) >= 0) last_owned = c;
-    /* (the reads shared with other ranks first: their candidate records travel while the rank's own files run) */
-    for (int c = 0; c <= last_owned; c++) if (r->chunks[c].n_shares > 1 && share_of(&r->chunks[c], r->o.rank) >= 0) r->list[r->n_list++] = c;
-    for (int c = 0; c <= last_owned; c++) if (r->chunks[c].n_shares <= 1 && (share_of(&r->chunks[c], r->o.rank) >= 0 || r->o.file_order)) r->list[r->n_list++] = c;
+    for (int c = 0; c < r->n_chunks; c++) if (r->chunks[c].owner == r->o.rank) last_owned = c;
+    for (int c = 0; c <= last_owned; c++) if (r->chunks[c].owner == r->o.rank || r->o.file_order) r->list[r->n_list++] = c;
     r->parsed = (mtrh_batch **)calloc((size_t)r->n_list + 1, sizeof(mtrh_batch *));
     r->pstate = (int *)calloc((size_t)r->n_list + 1, sizeof(int));
     r->chunk_done = (int *)calloc((size_t)r->n_chunks + 1, sizeof(int));
@@ -608,32 +456,6 @@ int mtrh_run_owner(const mtrh_run *r, int chunk) { return chunk >= 0 && chunk < 
 int mtrh_run_round_of(const mtrh_run *r, int chunk) { return chunk >= 0 && chunk < r->n_chunks ? r->chunks[chunk].round : -1; }
 
 const char *mtrh_run_engine_path(const mtrh_run *r) { return r->eng.path; }
-int mtrh_run_has_split(const mtrh_run *r) { return r->has_split; }
-int mtrh_run_n_shares(const mtrh_run *r, int chunk) { return chunk >= 0 && chunk < r->n_chunks ? r->chunks[chunk].n_shares : 0; }
-int mtrh_run_share_rank(const mtrh_run *r, int chunk, int s) { return chunk >= 0 && chunk < r->n_chunks && s >= 0 && s < r->chunks[chunk].n_shares ? r->chunks[chunk].shares[s] : -1; }
-
-/* round 0 of a run that shares long reads: this rank's candidate records (blocks until its shares are searched) */
-uint8_t *mtrh_run_candidates_blob(mtrh_run *r, size_t *bytes)
-{
-    pthread_mutex_lock(&r->mu);
-    while (!r->cand_out_ready && !r->device_done) pthread_cond_wait(&r->cv_res, &r->mu);
-    uint8_t *out = r->cand_out; *bytes = r->cand_out_bytes;
-    r->cand_out = NULL; r->cand_out_bytes = 0;
-    pthread_mutex_unlock(&r->mu);
-    if (!out) { out = (uint8_t *)malloc(1); *bytes = 0; }
-    return out;
-}
-
-void mtrh_run_feed(mtrh_run *r, const uint8_t *const *blobs, const size_t *sizes, int n_blobs)
-{
-    pthread_mutex_lock(&r->mu);
-    r->fed = (uint8_t **)calloc((size_t)n_blobs + 1, sizeof(uint8_t *)); r->fed_bytes = (size_t *)calloc((size_t)n_blobs + 1, sizeof(size_t));
-    for (int k = 0; k < n_blobs; k++) { r->fed[k] = (uint8_t *)malloc(sizes[k] ? sizes[k] : 1); memcpy(r->fed[k], blobs[k], sizes[k]); r->fed_bytes[k] = sizes[k]; }
-    r->n_fed = n_blobs; r->fed_ready = 1;
-    pthread_cond_broadcast(&r->cv_res);
-    pthread_mutex_unlock(&r->mu);
-}
-
 void mtrh_run_timing(const mtrh_run *r, double *t_parse_wait, double *t_submit, double *t_fetch, double *t_kernel, long long *queries)
 {
     if (t_parse_wait) *t_parse_wait = r->t_parse_wait;
@@ -657,8 +479,6 @@ void mtrh_run_stop(mtrh_run *r)
     for (int f = 0; f < r->n_files; f++) mtrh_file_close(&r->files[f]);
     mtrh_engine_unload(&r->eng);
     pthread_mutex_destroy(&r->mu); pthread_cond_destroy(&r->cv_parse); pthread_cond_destroy(&r->cv_res);
-    for (int k = 0; k < r->n_fed; k++) free(r->fed[k]);
-    free(r->fed); free(r->fed_bytes); free(r->cand_out);
     free(r->files); free(r->chunks); free(r->list); free(r->parsed); free(r->pstate); free(r->chunk_done);
     free(r);
 }

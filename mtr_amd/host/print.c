@@ -246,7 +246,7 @@ static void print_one(mtrh_printer *p, mtrh_result *r)
         free(b.s);
     } else {
         pthread_mutex_lock(&p->mu);
-        p->job = f; p->done_slices = 0;
+        p->job = f; p->done_slices = 0; p->oom = 0;            /* (a failure belongs to the result whose slices it hit, not to every later one) */
         for (int s = 0; s <= slices; s++) p->slice_first[s] = (int)((int64_t)n * s / slices);
         for (int s = 0; s < slices; s++) p->slice_buf[s].n = 0;
         p->n_slices = slices; p->next_slice = 0;

@@ -140,10 +140,8 @@ mtrh_result *mtrh_result_deserialize(const uint8_t *blob, size_t bytes, size_t *
 
 /* ---- a round: what one gather carries ------------------------------------------------------------------------------------ */
 /* all results this rank produces for `round`, serialised one after the other (malloc'ed; *bytes = 0 if it owns nothing) */
-uint8_t *mtrh_run_candidates_blob(mtrh_run *r, size_t *bytes);
 uint8_t *mtrh_run_round_blob(mtrh_run *run, int round, size_t *bytes)
 {
-    if (mtrh_run_has_split(run) && round == 0) return mtrh_run_candidates_blob(run, bytes);      /* the candidate records of the shared reads */
     int owned = 0;
     const int nc = mtrh_run_n_chunks(run);
     for (int c = 0; c < nc; c++) if (mtrh_run_round_of(run, c) == round && mtrh_run_owner(run, c) == mtrh_run_rank(run)) owned++;

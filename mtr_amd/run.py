@@ -23,7 +23,6 @@ from __future__ import annotations
 import argparse
 import ctypes as C
 import os
-import socket
 import subprocess
 import sys
 
@@ -36,7 +35,7 @@ class Opts(C.Structure):
     _fields_ = [("print_alignment", C.c_int), ("manhattan", C.c_int), ("file_order", C.c_int), ("device", C.c_int),
                 ("min_match_ratio", C.c_float), ("rank", C.c_int), ("world", C.c_int), ("lpt", C.c_int),
                 ("chunk_bytes", C.c_size_t), ("parse_threads", C.c_int), ("print_threads", C.c_int),
-                ("engine_lib", C.c_char_p), ("split_bytes", C.c_size_t)]
+                ("engine_lib", C.c_char_p)]
 
 
 def load_host():
@@ -54,14 +53,6 @@ def load_host():
     lib.mtrh_run_owner.argtypes = [C.c_void_p, C.c_int]
     lib.mtrh_run_round_blob.restype = C.c_void_p
     lib.mtrh_run_round_blob.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
-    lib.mtrh_run_has_split.restype = C.c_int
-    lib.mtrh_run_has_split.argtypes = [C.c_void_p]
-    lib.mtrh_run_n_shares.restype = C.c_int
-    lib.mtrh_run_n_shares.argtypes = [C.c_void_p, C.c_int]
-    lib.mtrh_run_share_rank.restype = C.c_int
-    lib.mtrh_run_share_rank.argtypes = [C.c_void_p, C.c_int, C.c_int]
-    lib.mtrh_run_feed.restype = None
-    lib.mtrh_run_feed.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]
     lib.mtrh_run_stop.restype = None
     lib.mtrh_run_stop.argtypes = [C.c_void_p]
     lib.mtrh_printer_start_stdout.restype = C.c_void_p
@@ -90,9 +81,6 @@ def parse_args(argv):
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl with a GPU, else gloo)")
     ap.add_argument("--engine-lib", default=None, help="library implementing include/mtr_hip.h (default: mtr_amd/libmtr_hip.so)")
     ap.add_argument("--chunk-bytes", type=int, default=0, help="FASTA bytes per chunk (default 24 MiB)")
-    ap.add_argument("--split-bytes", type=int, default=0,
-                    help="several files: a file of at least this many bytes whose cost exceeds a rank's fair part is searched by several ranks "
-                         "(default: never - on MI355X a share of a long read takes 86 %% of the whole read's time, DESIGN.md)")
     ap.add_argument("--stats", action="store_true", help="rank 0 reports ranks seen / bytes gathered on stderr")
     ap.add_argument("--force-dist", action="store_true",
                     help="a single rank too joins a process group and goes through the collectives (under torchrun with one rank: RCCL on a one-GPU box)")
@@ -104,49 +92,84 @@ def parse_args(argv):
     return a
 
 
-def free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
 def spawn(n, argv):
-    """One child per rank, started before this process has touched a GPU; the exit status is the ranks' worst."""
-    port = free_port()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        env.setdefault("GPU_MAX_HW_QUEUES", "8")        # RCCL's streams + the two context streams: more than the runtime's default of 4 hardware queues (bench.py)
-        procs.append(subprocess.Popen([sys.executable, "-m", "mtr_amd.run", *argv], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    # A rank that dies (a refused allocation in the host library exits the process, a crash, a malformed blob on rank 0) leaves the
-    # others waiting in a collective until the communicator times out - minutes.  So: once any rank has ended badly the others get
-    # a few seconds to end by themselves, then they are ended.
+    """One child per rank, started before this process has touched a GPU; the exit status is the ranks' worst.
+
+    Rendezvous: a FileStore in a directory of this launch (init_method file://) - one node is the whole machine, and no port is ever
+    chosen ahead of the ranks: a port found by bind-and-close belongs to whoever binds it next, and the ranks need seconds to import
+    torch before rank 0 would listen (the EADDRINUSE that reddened round 3's GPU suite)."""
+    import shutil
+    import tempfile
     import time
-    codes = [None] * n
-    failed_at = None
-    while any(c is None for c in codes):
-        for i, p in enumerate(procs):
-            if codes[i] is None:
-                rc = p.poll()
-                if rc is not None:
-                    codes[i] = rc
-                    if rc != 0 and failed_at is None:
-                        failed_at = time.monotonic()
-        if failed_at is not None and time.monotonic() - failed_at > 5.0:
+    rdzv_dir = tempfile.mkdtemp(prefix=f"mtr_run_{os.getpid()}_")
+    procs = []
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MTR_RDZV_FILE=os.path.join(rdzv_dir, "store"))
+            for k in ("MASTER_ADDR", "MASTER_PORT"):            # the children rendezvous through the file, whatever the caller's environment says
+                env.pop(k, None)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            env.setdefault("GPU_MAX_HW_QUEUES", "8")        # RCCL's streams + the two context streams: more than the runtime's default of 4 hardware queues (bench.py)
+            procs.append(subprocess.Popen([sys.executable, "-m", "mtr_amd.run", *argv], env=env,
+                                          stdout=None if r == 0 else subprocess.DEVNULL))
+        # A rank that dies (a refused allocation in the host library exits the process, a crash, a malformed blob on rank 0) leaves the
+        # others waiting in a collective until the communicator times out - minutes.  So: once any rank has ended badly the others get
+        # a few seconds to end by themselves, then they are ended.
+        codes = [None] * n
+        failed_at = None
+        while any(c is None for c in codes):
             for i, p in enumerate(procs):
                 if codes[i] is None:
-                    p.kill()
-                    codes[i] = p.wait()
-        time.sleep(0.02)
-    return max((c if c >= 0 else 128 - c) for c in codes)
+                    rc = p.poll()
+                    if rc is not None:
+                        codes[i] = rc
+                        if rc != 0 and failed_at is None:
+                            failed_at = time.monotonic()
+            if failed_at is not None and time.monotonic() - failed_at > 5.0:
+                for i, p in enumerate(procs):
+                    if codes[i] is None:
+                        p.kill()
+                        codes[i] = p.wait()
+            time.sleep(0.02)
+        return max((c if c >= 0 else 128 - c) for c in codes)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+        shutil.rmtree(rdzv_dir, ignore_errors=True)
 
 
-def gather_bytes(dist, torch, payload: bytes, rank, world, dev, to_all=False):
-    """Variable-length byte strings to rank 0 (to every rank with to_all): an all_gather of the sizes, then one padded gather."""
+def join_process_group(dist, backend, rank, world):
+    """The ranks of one node meet through a file when this launcher started them (MTR_RDZV_FILE) or when nobody named a master
+    (--force-dist in a lone process); under torchrun through the store its agent already listens on (MASTER_ADDR / MASTER_PORT)."""
+    delay = float(os.environ.get("MTR_TEST_RDZV_DELAY", "0") or 0)    # tests: rank 0 arrives late (the round-3 failure needed that)
+    if delay > 0 and rank == 0:
+        import time
+        time.sleep(delay)
+    path = os.environ.get("MTR_RDZV_FILE")
+    own_dir = None
+    if not path and "MASTER_PORT" not in os.environ:
+        import tempfile
+        own_dir = tempfile.mkdtemp(prefix=f"mtr_run_{os.getpid()}_")
+        path = os.path.join(own_dir, "store")
+    if path:
+        dist.init_process_group(backend, init_method="file://" + path, rank=rank, world_size=world)
+    else:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return own_dir
+
+
+def leave_process_group(dist, own_dir):
+    dist.destroy_process_group()
+    if own_dir:
+        import shutil
+        shutil.rmtree(own_dir, ignore_errors=True)
+
+
+def gather_bytes(dist, torch, payload: bytes, rank, world, dev):
+    """Variable-length byte strings to rank 0: an all_gather of the sizes, then one padded gather."""
     size = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
     sizes = [torch.zeros_like(size) for _ in range(world)]
     dist.all_gather(sizes, size)
@@ -155,11 +178,8 @@ def gather_bytes(dist, torch, payload: bytes, rank, world, dev, to_all=False):
     buf = torch.zeros(width, dtype=torch.uint8, device=dev)
     if payload:
         buf[: len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
-    out = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 or to_all else None
-    if to_all:
-        dist.all_gather(out, buf)
-    else:
-        dist.gather(buf, out, dst=0)
+    out = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, out, dst=0)
     if out is None:
         return None, sizes
     return [out[r][: sizes[r]].cpu().numpy().tobytes() for r in range(world)], sizes
@@ -174,11 +194,10 @@ def worker(a):
     dist = torch = dev = None
     device_ordinal = 0
     report_fd = None
+    rdzv_own_dir = None
     dist_on = world > 1 or a.force_dist
     backend = None
     if dist_on:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
         import torch
         import torch.distributed as dist
         backend = a.backend or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -197,11 +216,10 @@ def worker(a):
         sys.stdout.flush()
         report_fd = os.dup(1)
         os.dup2(2, 1)
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        rdzv_own_dir = join_process_group(dist, backend, rank, world)
     o = Opts(print_alignment=int(a.align), manhattan=int(not a.pearson), file_order=int(a.file_order), device=device_ordinal,
              min_match_ratio=a.ratio, rank=rank, world=world, lpt=int(len(a.fasta) > 1), chunk_bytes=a.chunk_bytes,
-             parse_threads=0, print_threads=0, engine_lib=(a.engine_lib.encode() if a.engine_lib else None),
-             split_bytes=(a.split_bytes if a.split_bytes >= 0 else C.c_size_t(-1).value))
+             parse_threads=0, print_threads=0, engine_lib=(a.engine_lib.encode() if a.engine_lib else None))
     paths = (C.c_char_p * len(a.fasta))(*[p.encode() for p in a.fasta])
     if a.pearson and rank == 0:
         sys.stderr.write("Pearson's correlation coefficient distance in place of Manhattan distance.\n")
@@ -215,7 +233,7 @@ def worker(a):
         if run:
             lib.mtrh_run_stop(run)
         if dist_on:
-            dist.destroy_process_group()
+            leave_process_group(dist, rdzv_own_dir)
         return 1
     n_print = min(8, max(1, (os.cpu_count() or 2) // 2))
     printer = None
@@ -224,22 +242,11 @@ def worker(a):
     n_rounds = lib.mtrh_run_n_rounds(run)
     n_chunks = lib.mtrh_run_n_chunks(run)
     gathered = 0
-    has_split = bool(lib.mtrh_run_has_split(run))
-    exchanged = 0
     for t in range(n_rounds):
         nbytes = C.c_size_t()
         ptr = lib.mtrh_run_round_blob(run, t, C.byref(nbytes))
         payload = C.string_at(ptr, nbytes.value) if nbytes.value else b""
         _libc.free(ptr)
-        if has_split and t == 0:
-            # the reads that several ranks searched: every rank's candidate records go to every rank (the one that reports a read picks
-            # out its group's), then the rounds of results follow as without sharing
-            blobs, sizes = gather_bytes(dist, torch, payload, rank, world, dev, to_all=True)
-            exchanged = sum(sizes)
-            keep = [C.create_string_buffer(b, len(b)) if b else C.create_string_buffer(1) for b in blobs]
-            arr = (C.c_void_p * world)(*[C.cast(k, C.c_void_p) for k in keep])
-            lib.mtrh_run_feed(run, arr, (C.c_size_t * world)(*sizes), world)
-            continue
         if dist_on:
             blobs, sizes = gather_bytes(dist, torch, payload, rank, world, dev)
         else:
@@ -260,24 +267,22 @@ def worker(a):
         if not round_ok:
             lib.mtrh_run_stop(run)
             if dist_on:
-                dist.destroy_process_group()
+                leave_process_group(dist, rdzv_own_dir)
             return 2
     status = 0
     if rank == 0:
         status = lib.mtrh_printer_finish(printer, None)
         if a.stats:
             owners = sorted({lib.mtrh_run_owner(run, c) for c in range(n_chunks)})
-            shared = [lib.mtrh_run_n_shares(run, c) for c in range(n_chunks)]
             sys.stderr.write(f"[mtr_amd.run] ranks={world} ranks_with_chunks={len(owners)} chunks={n_chunks} rounds={n_rounds} gathered_bytes={gathered}"
-                             f" backend={backend or 'none'} shared_files={sum(1 for s in shared if s > 1)} max_shares={max(shared, default=1)}"
-                             f" candidate_bytes={exchanged}\n")
+                             f" backend={backend or 'none'}\n")
     lib.mtrh_run_stop(run)
     if dist_on:
         st = torch.tensor([status], dtype=torch.int64, device=dev)
         dist.broadcast(st, src=0)
         status = int(st.item())
         dist.barrier()
-        dist.destroy_process_group()
+        leave_process_group(dist, rdzv_own_dir)
     return status
 
 

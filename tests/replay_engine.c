@@ -21,7 +21,6 @@ struct mtr_ctx {
     int32_t n; int32_t *lens; uint8_t **codes; const entry **hit;
     int32_t *counts; uint8_t *blob; int64_t blob_bytes;
     int ran, fail_after;
-    int32_t share, n_shares; int shared; int64_t cand[3];
 };
 struct mtr_file_state { int dummy; };
 
@@ -108,40 +107,7 @@ mtr_status mtr_upload_batch_in_file(mtr_ctx *c, mtr_file_state *fs, const uint8_
     return look_up(c);
 }
 mtr_status mtr_run_resident_async(mtr_ctx *c) { if (!c || c->n <= 0) return MTR_ERR_BAD_ARG; c->ran = 1; return MTR_OK; }
-/* One read's ranges over several contexts: the stand-in has no ranges, so a share's "candidate records" are its (share, n_shares)
- * and the replay checks that the host brought back exactly one blob of every other share of the group - then answers from the table.
- * MTR_REPLAY_FAIL_SHARE=k: share k reports a matrix beyond WrapDPsize (the host then runs the read whole on the reporting rank). */
-#define REPLAY_CAND_MAGIC 0x52504c43414e4431ll
-mtr_status mtr_run_ranges_share(mtr_ctx *c, int32_t share, int32_t n_shares)
-{
-    if (!c || c->n <= 0 || n_shares < 1 || share < 0 || share >= n_shares) return MTR_ERR_BAD_ARG;
-    const char *f = getenv("MTR_REPLAY_FAIL_SHARE");
-    if (f && atoi(f) == share) { snprintf(c->err, sizeof c->err, "You need to increse the value of WrapDPsize. (replayed failure of a share)"); return MTR_ERR_DP_TOO_LARGE; }
-    c->share = share; c->n_shares = n_shares; c->shared = 1; c->ran = 0;
-    return MTR_OK;
-}
-mtr_status mtr_export_candidates(mtr_ctx *c, const uint8_t **out_blob, int64_t *out_bytes)
-{
-    if (!c || !c->shared) return MTR_ERR_BAD_ARG;
-    c->cand[0] = REPLAY_CAND_MAGIC; c->cand[1] = c->share; c->cand[2] = c->n_shares;
-    *out_blob = (const uint8_t *)c->cand; *out_bytes = sizeof c->cand;
-    return MTR_OK;
-}
-mtr_status mtr_replay_candidates(mtr_ctx *c, const uint8_t *const *blobs, const int64_t *bytes, int32_t n_blobs)
-{
-    if (!c || !c->shared) return MTR_ERR_BAD_ARG;
-    int seen[64] = { 0 };
-    if (n_blobs != c->n_shares - 1) { snprintf(c->err, sizeof c->err, "replay: %d candidate blobs for %d shares", n_blobs, c->n_shares); return MTR_ERR_BAD_ARG; }
-    for (int b = 0; b < n_blobs; b++) {
-        int64_t h[3];
-        if (bytes[b] != (int64_t)sizeof h) { snprintf(c->err, sizeof c->err, "replay: candidate blob of %lld bytes", (long long)bytes[b]); return MTR_ERR_BAD_ARG; }
-        memcpy(h, blobs[b], sizeof h);
-        if (h[0] != REPLAY_CAND_MAGIC || h[2] != c->n_shares || h[1] <= 0 || h[1] >= c->n_shares || seen[h[1] & 63]) { snprintf(c->err, sizeof c->err, "replay: wrong candidate blob (share %lld of %lld)", (long long)h[1], (long long)h[2]); return MTR_ERR_BAD_ARG; }
-        seen[h[1] & 63] = 1;
-    }
-    c->shared = 0; c->ran = 1;
-    return mtr_wait(c);
-}
+
 mtr_status mtr_wait(mtr_ctx *c)
 {
     if (!c) return MTR_ERR_BAD_ARG;

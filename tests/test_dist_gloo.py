@@ -1,8 +1,7 @@
-"""The N > 1 path on CPU: read sharding, the launcher's gather of variable-length result blobs (mtr_amd.run.gather_bytes: an
+"""The N > 1 path on CPU: the launcher's gather of variable-length result blobs (mtr_amd.run.gather_bytes: an
 all_gather of the sizes + one padded gather) with world_size 2 over gloo — the same code runs over RCCL with CUDA tensors on the
 GPU box — and the sharded generation of bench.py's strong-scaling read set."""
 import os
-import socket
 
 import numpy as np
 import pytest
@@ -11,30 +10,9 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from mtr_amd import synth
-from mtr_amd.dist import shard_bounds
 from mtr_amd.run import gather_bytes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def test_shard_bounds_balanced_and_contiguous():
-    rng = np.random.RandomState(0)
-    lens = rng.randint(500, 5000, size=1000)
-    for world in (1, 2, 3, 8):
-        b = shard_bounds(lens, world)
-        assert b[0] == 0 and b[-1] == len(lens) and len(b) == world + 1 and all(x <= y for x, y in zip(b, b[1:]))
-        tot = [int(lens[b[r]:b[r + 1]].sum()) for r in range(world)]
-        assert max(tot) - min(tot) <= 2 * lens.max()
-    assert shard_bounds([10], 4) == [0, 0, 0, 0, 1] or shard_bounds([10], 4)[-1] == 1
-    assert shard_bounds([], 2) == [0, 0, 0]
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
 
 
 def _payload(rank, rnd):
@@ -43,10 +21,8 @@ def _payload(rank, rnd):
     return rng.randint(0, 256, size=n).astype(np.uint8).tobytes()
 
 
-def _worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, store, q):
+    dist.init_process_group("gloo", init_method="file://" + store, rank=rank, world_size=world)     # no port picked ahead of the ranks
     for rnd in range(3):
         blobs, sizes = gather_bytes(dist, torch, _payload(rank, rnd), rank, world, torch.device("cpu"))
         assert sizes == [len(_payload(r, rnd)) for r in range(world)]
@@ -59,8 +35,8 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(120)
-def test_gather_bytes_world2_gloo():
-    world, port = 2, _free_port()
+def test_gather_bytes_world2_gloo(tmp_path):
+    world, port = 2, str(tmp_path / "store")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]

@@ -139,6 +139,24 @@ def test_pure_repeat_with_unit_250_to_256_as_longest_read(unit_len):
     assert any(r[3] == unit_len for r in want[0])
 
 
+def _torchrun(world, args, env, timeout):
+    """python -m torch.distributed.run as the driver starts bench.py (a named master port: torchrun's agent listens on it before any
+    rank starts).  The port is taken below the kernel's ephemeral range, so no outgoing connection can sit on it; should a listener of
+    something else hold it, the launch is repeated on the next port instead of failing the suite on plumbing."""
+    p = None
+    for attempt in range(6):
+        port = 29500 + (os.getpid() * 7 + attempt * 131 + _torchrun.calls * 17) % 400
+        _torchrun.calls += 1
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), *args], capture_output=True, env=env, timeout=timeout, cwd=ROOT)
+        if p.returncode == 0 or not any(w in p.stderr for w in (b"EADDRINUSE", b"Address already in use", b"address already in use")):
+            return p
+    return p
+
+
+_torchrun.calls = 0
+
+
 @pytest.mark.timeout(900)
 def test_bench_strong_scaling_gathers_the_oracles_record_stream():
     """BASELINE config 4 as bench.py measures it with N ranks: 100 000 reads in contiguous blocks, every rank's record tables
@@ -152,9 +170,7 @@ def test_bench_strong_scaling_gathers_the_oracles_record_stream():
     env = {k: v for k, v in os.environ.items() if k not in ("MTR_LIB", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
     if n == 1:
         env["MTR_BENCH_BACKEND"] = "gloo"
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--strong", "c4", "--steps", "1", "--warmup", "1"],
-                       capture_output=True, env=env, timeout=800, cwd=ROOT)
+    p = _torchrun(world, [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--strong", "c4", "--steps", "1", "--warmup", "1"], env, 800)
     assert p.returncode == 0, p.stderr.decode()[-800:]
     line = json.loads(p.stdout.decode().strip().splitlines()[-1])
     assert line["n_gpus"] == world and line["scaling"] == "strong"
@@ -163,11 +179,10 @@ def test_bench_strong_scaling_gathers_the_oracles_record_stream():
 
 
 # ---- RCCL on the one-GPU box: one rank under torch.distributed.run, backend "nccl"  -------------------------------
-def _torchrun_one_rank(args, port, extra_env=None, timeout=800):
+def _torchrun_one_rank(args, extra_env=None, timeout=800):
     env = {k: v for k, v in os.environ.items() if k not in ("MTR_LIB", "MTR_REPLAY_TABLE", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MTR_BENCH_BACKEND")}
     env.update(extra_env or {})
-    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                           "--master-port", str(port), *args], capture_output=True, env=env, timeout=timeout, cwd=ROOT)
+    return _torchrun(1, args, env, timeout)
 
 
 @pytest.mark.timeout(900)
@@ -176,7 +191,7 @@ def test_rccl_weak_step_of_the_bench_with_one_rank():
     with ONE rank: what an 8-GPU run executes per rank, on the box the suite has."""
     import json
     p = _torchrun_one_rank([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--reads", "3000", "--no-cli", "--no-latency",
-                            "--cpu-sample", "0"], 29541, {"MTR_BENCH_FORCE_DIST": "1"})
+                            "--cpu-sample", "0"], {"MTR_BENCH_FORCE_DIST": "1"})
     assert p.returncode == 0, p.stderr.decode()[-800:]
     line = json.loads(p.stdout.decode().strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["exchange"]["backend"] == "nccl" and line["exchange"]["forced_on_one_rank"] is True
@@ -189,7 +204,7 @@ def test_rccl_strong_c4_10000_reads_match_the_oracles_hash():
     (tests/golden/c4_10000_wire.json, made by tests/golden/make_c4_wire_hash.py -n 10000)."""
     import json
     p = _torchrun_one_rank([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--strong", "c4", "--strong-reads", "10000", "--steps", "1", "--warmup", "1"],
-                           29542, {"MTR_BENCH_FORCE_DIST": "1"})
+                           {"MTR_BENCH_FORCE_DIST": "1"})
     assert p.returncode == 0, p.stderr.decode()[-800:]
     line = json.loads(p.stdout.decode().strip().splitlines()[-1])
     st = line["strong"]
@@ -201,66 +216,12 @@ def test_rccl_strong_c4_10000_reads_match_the_oracles_hash():
 def test_rccl_launcher_with_one_rank_force_dist():
     """python -m mtr_amd.run --force-dist under torch.distributed.run with one rank: process group over RCCL, the size all_gather,
     the padded gather and the per-round verdict broadcast run on the GPU box; stdout byte-identical to the reference's."""
-    p = _torchrun_one_rank(["-m", "mtr_amd.run", "--force-dist", "--stats", "--chunk-bytes", "20000", gu.input_path("synth_c4")], 29543)
+    p = _torchrun_one_rank(["-m", "mtr_amd.run", "--force-dist", "--stats", "--chunk-bytes", "20000", gu.input_path("synth_c4")])
     assert p.returncode == 0, p.stderr.decode()[-800:]
     assert p.stdout == golden("synth_c4", "default")
     err = p.stderr.decode()
     assert "ranks=1" in err and "backend=nccl" in err, err[-400:]
     files = [gu.input_path(n) for n in BUNDLED[:6]]
-    p = _torchrun_one_rank(["-m", "mtr_amd.run", "--force-dist", "-a", *files], 29544)            # several files: one round, -a blobs
+    p = _torchrun_one_rank(["-m", "mtr_amd.run", "--force-dist", "-a", *files])            # several files: one round, -a blobs
     assert p.returncode == 0, p.stderr.decode()[-800:]
     assert p.stdout == b"".join(golden(n, "a") for n in BUNDLED[:6])
-
-
-# ---- one long read's ranges over several contexts (config 5's 90-140 kb reads; VERDICT r2) ----------------------------------
-@pytest.mark.timeout(900)
-@pytest.mark.parametrize("n_shares", [2, 3, 8])
-def test_ranges_of_a_read_shared_by_contexts_give_the_reads_records(n_shares):
-    """mtr_run_ranges_share / mtr_export_candidates / mtr_replay_candidates: N contexts hold the same reads, each searches the ranges
-    t % N == share, one of them replays the reference's loop with everybody's candidates.  The records must be those of the oracle
-    (and of mtr_run_resident) - on bundled multi-repeat reads, in Pearson mode as config 5 runs them, and on a small mixed batch."""
-    from tests.oracle_binding import Oracle
-    import torch
-    torch.cuda.init()
-    cases = [([c for _, c in gu.read_fasta(gu.input_path(n))], False) for n in ("2_5_10_20_set", "10_50", "worm_chrI")]
-    cases.append(([c for _, c in synth.make_reads("c4", 12, 77)] + [np.tile(np.array([0, 1], np.uint8), 300)], True))
-    for reads, manhattan in cases:
-        orc = Oracle(manhattan)
-        want = [orc.process(c) for c in reads]
-        orc.close()
-        engs = [mtr_amd.Engine(manhattan=manhattan) for _ in range(min(n_shares, 3))]       # (contexts are reused for the shares of an 8-way split)
-        blobs = []
-        for sh in range(n_shares):
-            e = engs[sh % len(engs)] if sh > 0 else engs[0]
-            if sh > 0 and e is engs[0]:
-                e = engs[1]
-            e.upload(reads)
-            e.run_share(sh, n_shares)
-            blobs.append(e.export_candidates())
-        engs[0].upload(reads)
-        engs[0].run_share(0, n_shares)
-        engs[0].replay_candidates(blobs)
-        got = engs[0].fetch()
-        for i in range(len(reads)):
-            assert [tuple(r) for r in got[i]] == want[i], (n_shares, i)
-        assert sum(len(w) for w in want) > 0
-        for e in engs:
-            e.close()
-
-
-@pytest.mark.timeout(1800)
-def test_launcher_spreads_a_long_read_over_ranks():
-    """config 5 with more ranks than long reads: the 100+ kb read of a file is searched by a group of ranks (here: ranks sharing the
-    one GPU, gloo carrying the candidate round) and reported by the group's first rank - stdout byte-identical to the reference's."""
-    from tests.test_run_gloo import SHARED
-    for big, mode, flags in (("worm_chrII_1", "p", ["-p"]), ("2_5_10_20_50_100_200_set", "default", []), ("2_5_10_20_50_100_200_set", "a", ["-a"])):
-        names = ["3_5", big]
-        p = _run([*flags, "--split-bytes", "50000", *[gu.input_path(n) for n in names]], 2, "gloo")
-        assert p.returncode == 0, p.stderr.decode()[-800:]
-        assert p.stdout == b"".join(golden(n, mode) for n in names), (big, mode)
-        stats = [l for l in p.stderr.decode().splitlines() if l.startswith("[mtr_amd.run]")][0]
-        assert "shared_files=1 " in stats and "max_shares=2 " in stats and "candidate_bytes=0" not in stats, stats
-    p = _run(["-p", "--split-bytes", "50000", *[gu.input_path(n) for n in SHARED]], 4, "gloo")              # both long reads shared, one of them four ways
-    assert p.returncode == 0, p.stderr.decode()[-800:]
-    assert p.stdout == b"".join(golden(n, "p") for n in SHARED)
-    assert "max_shares=4 " in p.stderr.decode()

@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--strong-reads", type=int, default=100000)
     ap.add_argument("--cpu-sample", type=int, default=2000, help="reads timed on the CPU baseline (0 = skip); 2000 reads ~ 15 s on one core")
     ap.add_argument("--config", default=None, choices=["c3"], help="a secondary line for another BASELINE config: c3 = 100 reads of unit 200 x 200 copies (L ~ 42 kb), -a on in the command-line leg")
+    ap.add_argument("--no-secondary", action="store_true", help="the default line without its secondary.c3 object (BASELINE config 3 measured in a child process)")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-cli", action="store_true")
     a = ap.parse_args()
@@ -466,6 +467,19 @@ def main():
             out["strong"] = {"ranks_seen": 1, "reads_per_rank": [n_local], "records": int(counts.sum()), "sha256": hx,
                              "matches_oracle": (known["sha256"] == hx) if known else None,
                              "known_answer": "tests/golden/c4_100k_wire.json (CPU oracle)" if known else None}
+        if a.config == "c3" and world == 1:
+            # the launch's record stream against the CPU oracle's known answer (tests/golden/make_c4_wire_hash.py --config c3 -n 100)
+            data, counts = eng.fetch_packed()
+            known = None
+            try:
+                with open(os.path.join(ROOT, "tests", "golden", f"c3_{n_local}_wire.json")) as fh:
+                    known = json.load(fh)
+            except Exception:
+                pass
+            hx = hashlib.sha256(data).hexdigest()
+            out["matches_oracle"] = (known["sha256"] == hx and known["records"] == int(counts.sum())) if known else None
+            out["record_stream"] = {"records": int(counts.sum()), "wire_bytes": len(data), "sha256": hx,
+                                    "known_answer": f"tests/golden/c3_{n_local}_wire.json (CPU oracle, pinned to the reference)" if known else None}
         if world == 1 and not a.no_latency:
             lat = []
             e2 = mtr_amd.Engine(device=local_rank)
@@ -501,6 +515,22 @@ def main():
                 out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline"]["all_cores"]["value"]
             if out.get("value_cli"):
                 out["speedup_cli_vs_cpu_1core"] = out["value_cli"] / out["cpu_baseline"]["value"]
+        if world == 1 and not dist_on and not a.strong and a.config is None and not a.no_secondary:
+            # BASELINE config 3 (unit 200 x 200 copies, L ~ 42 kb, -a on in its command-line leg) in the driver-run line: measured by a
+            # child process after this one has given its contexts back, its whole JSON line kept under secondary.c3
+            for e in engs:
+                e.close()
+            engs.clear()
+            torch.cuda.empty_cache()
+            t0 = time.perf_counter()
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "c3", "--steps", "4", "--warmup", "1", "--cpu-sample", str(min(a.cpu_sample, 6))]
+                               + (["--no-cli"] if a.no_cli else []), capture_output=True, text=True, cwd=ROOT)
+            try:
+                sec = json.loads(p.stdout.strip().splitlines()[-1])
+            except Exception:
+                sec = {"error": (p.stderr or p.stdout)[-400:], "returncode": p.returncode}
+            sec["wall_s"] = time.perf_counter() - t0
+            out["secondary"] = {"c3": sec}
         print(json.dumps(out))
     for e in engs:
         e.close()

@@ -5,6 +5,7 @@ mixed-unit reads of mtr_amd.synth config "c4" (seed 4).  bench.py --strong c4 co
 ranks with it: the multi-GPU result must be bit-identical to the reference's, whatever N.
 
   python tests/golden/make_c4_wire_hash.py [-j 6]      -> tests/golden/c4_100k_wire.json   (~3 min on 6 cores)
+  python tests/golden/make_c4_wire_hash.py --config c3 -n 100   -> tests/golden/c3_100_wire.json (config 3's shape: 100 reads of 42 kb)
 """
 import argparse
 import hashlib
@@ -38,10 +39,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("-j", type=int, default=6)
     ap.add_argument("-n", type=int, default=100000)
+    ap.add_argument("--config", default="c4", help="c4 (seed 4); c3 = BASELINE config 3's shape, seed 3 (bench.py's secondary.c3: -n 100)")
     a = ap.parse_args()
     from mtr_amd import synth
-    READS = synth.make_reads("c4", a.n, 4)
-    step = 500
+    seed = {"c4": 4, "c3": 3}[a.config]
+    READS = synth.make_reads(a.config, a.n, seed)
+    step = 500 if a.config == "c4" else 2
     jobs = [(lo, min(lo + step, a.n)) for lo in range(0, a.n, step)]
     h = hashlib.sha256()
     total_bytes = total_rec = 0
@@ -50,9 +53,9 @@ def main():
             h.update(blob)
             total_bytes += len(blob)
             total_rec += nrec
-    out = {"config": "c4", "seed": 4, "n_reads": a.n, "records": total_rec, "wire_bytes": total_bytes, "sha256": h.hexdigest(),
+    out = {"config": a.config, "seed": seed, "n_reads": a.n, "records": total_rec, "wire_bytes": total_bytes, "sha256": h.hexdigest(),
            "sum_len": int(sum(len(c) for _, c in READS)), "made_by": "tests/golden/make_c4_wire_hash.py (CPU oracle)"}
-    path = os.path.join(ROOT, "tests", "golden", "c4_100k_wire.json" if a.n == 100000 else f"c4_{a.n}_wire.json")
+    path = os.path.join(ROOT, "tests", "golden", "c4_100k_wire.json" if (a.n == 100000 and a.config == "c4") else f"{a.config}_{a.n}_wire.json")
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out))

@@ -135,6 +135,21 @@ def test_config3_shape_16_reads_against_the_oracle():
 
 
 @pytest.mark.timeout(900)
+def test_config3_at_full_size_record_stream_is_the_oracles():
+    """BASELINE config 3 as bench.py measures it (its default line's secondary.c3 runs the same child): 100 reads of unit 200 x 200 copies,
+    the launch's record stream in wire form against the CPU oracle's known answer (tests/golden/c3_100_wire.json)."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("MTR_LIB", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c3", "--steps", "1", "--warmup", "1", "--no-cli", "--no-latency", "--cpu-sample", "0"],
+                       capture_output=True, env=env, timeout=800, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["matches_oracle"] is True and line["record_stream"]["records"] == 1724, line.get("record_stream")
+    assert "config 3" in line["metric"] and line["config"]["reads_per_gpu"] == 100
+
+
+@pytest.mark.timeout(900)
 def test_cli_alignments_on_a_config3_shaped_read(tmp_path):
     from tests.oracle_binding import ORACLE_DIR
     subprocess.run(["make", "-s", "-C", ORACLE_DIR, "oracle"], check=True)

@@ -126,6 +126,25 @@ def cpu_baseline(reads, n_sample):
     return one
 
 
+def empty_hip_program():
+    """What a process pays on THIS box before its first kernel has run - a program that initialises the HIP runtime, creates a stream and runs an
+    empty kernel (tests/dev/hip_init_probe.hip, built by __graft_entry__.build()): the floor under the command line's start-up, three runs."""
+    exe = os.path.join(ROOT, "tests", "dev", "hip_init_probe")
+    if not os.path.exists(exe):
+        return None
+    out = []
+    for _ in range(3):
+        try:
+            p = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+            ms = [float(ln.split(" ms")[0].split()[-1]) for ln in p.stdout.splitlines() if ln.startswith("first kernel")]
+            if ms:
+                out.append(ms[0] / 1e3)
+        except Exception:
+            pass
+    return {"seconds_until_first_kernel_done": out, "min": min(out), "max": max(out),
+            "note": "hipInit + stream + first kernel of an EMPTY program on this box in this run; the runtime's own start-up, which varies from process to process"} if out else None
+
+
 def cli_rate(reads, n, flags=()):
     """wall clock of the command line on a FASTA of the first n reads (page cache warm), best of 3"""
     from mtr_amd import synth
@@ -419,7 +438,12 @@ def main():
                                  "note": "a launch that has the GPU to itself (the warm-up steps)"},
             "kernels_mode_timed": eng.last_mode(),
             "work_per_launch": {k: cnt[k] for k in ("dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_dp_cells", "memo_hits", "memo_cells",
-                                                    "kmer_tables", "tables_skipped", "kmer_lookups", "ranges_executed", "records", "traceback_steps")},
+                                                    "kmer_tables", "tables_skipped", "kmer_lookups", "ranges_executed", "records", "traceback_steps", "revisions_shared")},
+            "quad_passes": {"note": "four-per-wavefront DP passes (dp_quad.hip.inc): bytes of cell matrix written (every row of all four 16-lane groups up to the pass's longest member) "
+                                    "per cell of the DPs the pass was run for; alignments: one byte holds the cell of both parameter sets",
+                            "alignments_bytes_per_cell_pair": (cnt["qpass_bytes_dp2"] / cnt["qpass_cells_dp2"]) if cnt["qpass_cells_dp2"] else None,
+                            "revisions_bytes_per_cell": (cnt["qpass_bytes_rev"] / cnt["qpass_cells_rev"]) if cnt["qpass_cells_rev"] else None,
+                            "alignments_bytes": cnt["qpass_bytes_dp2"], "revisions_bytes": cnt["qpass_bytes_rev"]},
             "reference_work_per_launch": {k: ref_cnt[k] for k in ("dp_calls", "dp_cells", "revise_dp_calls", "revise_dp_cells", "memo_hits", "memo_cells", "ranges_executed", "records")},
             "roofline": {"bound": "valu-issue",
                          "kernel": "one launch = the staged chain (mtr_k1_ranges, mtr_k_walks, mtr_k_walks_k, mtr_k_gather, mtr_k_dp2_quads, mtr_k_dp2_waves, "
@@ -507,7 +531,13 @@ def main():
             c10 = cli_rate(reads, 10 * len(reads))
             out["value_cli"] = c10.get("reads_per_s")
             out["cli"] = {"note": "mtr_amd/host/mTR <fasta> > /dev/null, wall clock incl. process start and HIP initialisation; best of 3",
-                          "one_batch": c1, "ten_batches": c10}
+                          "one_batch": c1, "ten_batches": c10, "empty_hip_program": empty_hip_program()}
+            try:        # the command line's own part: from the first device context (the runtime is up) to the end of the run
+                st = c10["stamps_s"]
+                own = st["run stopped"] - st["first device context created"]
+                out["cli"]["ten_batches_after_runtime_start"] = {"seconds": own, "reads_per_s": c10["reads"] / own}
+            except Exception:
+                pass
         if world == 1 and a.cpu_sample > 0 and not a.strong:
             out["cpu_baseline"] = cpu_baseline(reads, a.cpu_sample if a.config is None else min(a.cpu_sample, 6))     # (a config-3 read is ~2.6 s of CPU)
             out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"]

@@ -210,11 +210,13 @@ mtr_status mtr_get_kernel_times(const mtr_ctx *ctx, mtr_kernel_time *out, int32_
  * [0] wrap-around DP calls, [1] DP cells, [2] DP rows, [3] revision DP calls, [4] revision DP cells,
  * [5] k-mer tables built, [6] k-mer look-ups, [7] candidate ranges, [8] ranges executed, [9] records,
  * [10] DI passes, [11] DI positions, [12] traceback steps, [13] undefined-behaviour guards hit. */
-#define MTR_N_COUNTERS 48   /* [16..31]: shader-clock cycles per phase summed over wavefronts (total, DP forward, DP
+#define MTR_N_COUNTERS 56   /* [16..31]: shader-clock cycles per phase summed over wavefronts (total, DP forward, DP
                              * traceback, table build, seed list, walks, polish, revision votes, slot copies,
                              * revision DP forward / traceback, range-finder phases);
                              * [32] wrap_around_DP calls answered from the per-range memo (same window, same unit),
-                             * [33] DP cells those calls would have filled, [34] k-mer tables proven unnecessary */
+                             * [33] DP cells those calls would have filled, [34] k-mer tables proven unnecessary;
+                             * [48..51] four-per-wavefront passes: cell bytes written / cells of the DPs served, alignments then revisions;
+                             * [52] revisions answered by an identical revision of the same range */
 mtr_status mtr_get_counters(const mtr_ctx *ctx, int64_t *out, int32_t n);
 
 #ifdef __cplusplus

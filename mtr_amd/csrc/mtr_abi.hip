@@ -14,6 +14,7 @@
 // There is no CPU path: every entry point needs the HIP device the context was created on.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -209,7 +210,8 @@ extern "C" mtr_status mtr_file_state_skip(mtr_file_state *fs, const uint8_t *bas
 // test knob: MTR_DP16_MAX_ROWS=0 sends every DP through the 32-bit kernels (the fallbacks of reads > 64 kb)
 static int dp16_max_rows() { const char *e = getenv("MTR_DP16_MAX_ROWS"); return e ? atoi(e) : 0x7fffffff; }
 static bool dbg() { static int v = -1; if (v < 0) v = getenv("MTR_DEBUG") ? 1 : 0; return v == 1; }
-#define DBG(...) do { if (dbg()) { fprintf(stderr, "[mtr] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+static double dbg_ms() { static const auto t0 = std::chrono::steady_clock::now(); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+#define DBG(...) do { if (dbg()) { fprintf(stderr, "[mtr +%.1f ms] ", dbg_ms()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return MTR_ERR_HIP; } } while (0)
@@ -285,6 +287,7 @@ extern "C" mtr_status mtr_create(int device, int manhattan, float min_match_rati
     if (!out) return MTR_ERR_BAD_ARG;
     *out = nullptr;
     int ndev = 0;
+    DBG("mtr_create: begin");
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return MTR_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return MTR_ERR_NO_DEVICE;
     mtr_ctx *ctx = new (std::nothrow) mtr_ctx();
@@ -292,6 +295,7 @@ extern "C" mtr_status mtr_create(int device, int manhattan, float min_match_rati
     ctx->device = device; ctx->manhattan = manhattan ? 1 : 0; ctx->min_ratio = min_match_ratio;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    DBG("mtr_create: runtime up, device selected");
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 4; i++) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
     for (int i = 2; ok && i < MTR_N_KERNEL_TIMES; i++) ok = hipEventCreate(&ctx->ev_ph[i]) == hipSuccess;
@@ -313,6 +317,7 @@ extern "C" mtr_status mtr_create(int device, int manhattan, float min_match_rati
     } else ok = false;
     if (!ok) { mtr_destroy(ctx); return MTR_ERR_NO_DEVICE; }
     *out = ctx;
+    DBG("mtr_create: stream, events, small buffers, MT stream ready");
     return MTR_OK;
 }
 
@@ -439,6 +444,7 @@ static mtr_status upload_batch(mtr_ctx *ctx, mtr_file_state *fs, const uint32_t 
     ctx->lens.assign(lens, lens + n);
     ctx->n_reads = n; ctx->Lmax = Lmax;
     ctx->max_rec = 16 + Lmax / 100;
+    DBG("upload_batch: %d reads checked and ordered", n);
     HIPCHK(ensure_dev(ctx, ctx->d_packed, ((size_t)words + 80) * 4));      // + 80: the DP stages 64-word blocks, the last block must stay readable
     HIPCHK(ensure_dev(ctx, ctx->d_woff, (size_t)n * 8)); HIPCHK(ensure_dev(ctx, ctx->d_lens, (size_t)n * 4)); HIPCHK(ensure_dev(ctx, ctx->d_order, (size_t)n * 4));
     HIPCHK(ensure_dev(ctx, ctx->d_roff, ((size_t)n + 1) * 8)); HIPCHK(ensure_dev(ctx, ctx->d_rcount, (size_t)n * 4));
@@ -448,6 +454,7 @@ static mtr_status upload_batch(mtr_ctx *ctx, mtr_file_state *fs, const uint32_t 
     HIPCHK(ensure_dev(ctx, ctx->d_reccount, (size_t)n * 4));
     HIPCHK(ensure_dev(ctx, ctx->d_recoff, ((size_t)n + 1) * 8));
     HIPCHK(ensure_dev(ctx, ctx->d_item_off, ((size_t)n + 1) * 8));
+    DBG("upload_batch: batch buffers ready");
     HIPCHK(hipMemcpyAsync(ctx->d_packed, packed, (size_t)words * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_packed + words, 0, 80 * 4, ctx->stream));
     ctx->packed_words = (long long)words + 80;
@@ -461,6 +468,7 @@ static mtr_status upload_batch(mtr_ctx *ctx, mtr_file_state *fs, const uint32_t 
         HIPCHK(hipMemcpyAsync(ctx->d_tail_off, tail_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    DBG("upload_batch: copies done");
     return MTR_OK;
 }
 
@@ -751,7 +759,9 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         ctx->last_staged = false;
         return launch_reads(ctx);
     }
+    DBG("launch_staged: chain buffers ready (arena %.0f MB)", (double)s.arena_cap / 1e6);
     mtr_status st = ensure_scratch(ctx, std::max(std::max(total, total_dp), parts ? (size_t)n * y1.total : (size_t)0)); if (st != MTR_OK) return st;
+    DBG("launch_staged: scratch ready (%.0f MB)", (double)ctx->scratch_bytes / 1e6);
     K1Args a1{}; k1_args(ctx, a1, per_wave);
     K2Args a{}; k2_args(ctx, a, per_wave);
     HIPCHK(hipMemsetAsync(ctx->d_trace_n, 0, sizeof(unsigned), ctx->stream));
@@ -809,7 +819,21 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev_ph[5], ctx->stream));       // selection
     if (s.quad_min > 0) {
-        // four revisions per wavefront: mtr_k_select has binned them (the alignments' sort buffers are free again)
+        // four revisions per wavefront.  First every revision is polished (a work item each), then the revisions of a range whose polished
+        // states are equal are joined and the ones that run are binned (the alignments' sort buffers are free again)
+        {
+            K2Args ap = a;
+            ap.cells_cap = 256;                             // (polish aligns nothing: the scratch layout of the walks)
+            const size_t pw = k2_layout(ctx->Lmax, ap.cells_cap).total;
+            size_t tw = 0;
+            int wp = pick_waves(ctx, std::max(n * 8, ctx->n_cu * 16), waves_per_cu(), pw, &tw);
+            if (tw > ctx->scratch_bytes) wp = std::min(wp, waves);
+            ap.scratch_per_wave = pw;
+            hipLaunchKernelGGL(mtr_k_polish, dim3((unsigned)capped(wp, 256)), dim3(64), 0, ctx->stream, ap, s);
+            HIPCHK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(mtr_k_rev_share, dim3((unsigned)capped(ctx->n_cu * 32, 64)), dim3(64), 0, ctx->stream, a, s);
+        HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(mtr_k_qbins, dim3(1), dim3(1024), 0, ctx->stream, s, 1);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(mtr_k_rscatter, dim3((unsigned)capped(512, 16384)), dim3(256), 0, ctx->stream, s);
@@ -826,6 +850,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     hipLaunchKernelGGL(mtr_k_replay, dim3((unsigned)std::min(n, 65535)), dim3(64), 0, ctx->stream, a, sp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+    DBG("launch_staged: every kernel of the chain enqueued");
     return MTR_OK;
 }
 

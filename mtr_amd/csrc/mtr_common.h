@@ -44,7 +44,10 @@ enum { CNT_DP_CALLS = 0, CNT_DP_CELLS, CNT_DP_ROWS, CNT_REV_CALLS, CNT_REV_CELLS
        // work the kernel proved it did not have to repeat (results identical by construction)
        CNT_MEMO_HITS = 32, CNT_MEMO_CELLS, CNT_TABLES_SKIPPED, CYC_TB_REFILL, CNT_TB_REFILLS, CNT_WALK_STEPS, CNT_WALK_SLOW, CYC_WALK_SLOW,
        CNT_WALK_CALLS = 40, CNT_WALK_CLOSED, CYC_WALK_FAST, CNT_SPARE43, CNT_SPARE44, CNT_SPARE45, CNT_SPARE46, CNT_SPARE47,
-       CNT_N = 48 };
+       // the four-per-wavefront passes (dp_quad.hip.inc): bytes of cell matrix a pass writes (every row of every 16-lane group up to the
+       // pass's longest member) against the cells of the DPs it was run for; revisions answered by another revision of their range
+       CNT_QPASS_BYTES_DP2 = 48, CNT_QPASS_CELLS_DP2, CNT_QPASS_BYTES_REV, CNT_QPASS_CELLS_REV, CNT_REV_SHARED, CNT_SPARE53, CNT_SPARE54, CNT_SPARE55,
+       CNT_N = 56 };
 
 // status word values written by the kernels (first error wins)
 enum { DEV_OK = 0, DEV_ERR_RANGE_OVERFLOW = 1, DEV_ERR_RECORD_OVERFLOW = 2, DEV_ERR_DP_TOO_LARGE = 3, DEV_ERR_INTERNAL = 4,

@@ -216,7 +216,8 @@ mtr_status mtr_get_kernel_times(const mtr_ctx *ctx, mtr_kernel_time *out, int32_
                              * [32] wrap_around_DP calls answered from the per-range memo (same window, same unit),
                              * [33] DP cells those calls would have filled, [34] k-mer tables proven unnecessary;
                              * [48..51] four-per-wavefront passes: cell bytes written / cells of the DPs served, alignments then revisions;
-                             * [52] revisions answered by an identical revision of the same range */
+                             * [52] revisions answered by an identical revision of the same range, [53] reads the chain sent back to the per-read kernel,
+                             * [54] candidate ranges the chain searched ([8]: the ranges the reference's loop reaches) */
 mtr_status mtr_get_counters(const mtr_ctx *ctx, int64_t *out, int32_t n);
 
 #ifdef __cplusplus

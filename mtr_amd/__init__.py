@@ -26,7 +26,7 @@ COUNTER_NAMES = ["dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_d
                  "cyc_k1_dedup", "cyc_k1_total",
                  "memo_hits", "memo_cells", "tables_skipped", "cyc_tb_refill", "tb_refills", "walk_steps", "walk_slow_steps", "cyc_walk_slow",
                  "walk_calls", "walk_closed", "cyc_walk_fast", "spare43", "spare44", "spare45", "spare46", "spare47",
-                 "qpass_bytes_dp2", "qpass_cells_dp2", "qpass_bytes_rev", "qpass_cells_rev", "revisions_shared", "spare53", "spare54", "spare55"]
+                 "qpass_bytes_dp2", "qpass_cells_dp2", "qpass_bytes_rev", "qpass_cells_rev", "revisions_shared", "reads_sent_back", "ranges_searched", "spare55"]
 EXPORTS = ["mtr_create", "mtr_destroy", "mtr_last_error", "mtr_abi_version", "mtr_process_batch", "mtr_free_results",
            "mtr_upload_batch", "mtr_run_resident", "mtr_fetch_results", "mtr_get_kernel_times", "mtr_get_counters",
            "mtr_test_ranges", "mtr_test_wrap_dp", "mtr_test_last_mode", "mtr_set_trace", "mtr_get_trace",

@@ -62,6 +62,8 @@ struct mtr_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
     hipEvent_t ev_ph[MTR_N_KERNEL_TIMES] = {};     // phase boundaries of the staged chain (ev_ph[p] = end of phase p, p = 2..7)
+    hipEvent_t ev_ph2[MTR_N_KERNEL_TIMES] = {};    // the same for the chain's second pass (ev_ph2[2] = its start); last_two_pass: they were recorded
+    bool last_two_pass = false;
     std::string err;
     int n_cu = 256;
     uint8_t *d_mt = nullptr;
@@ -90,6 +92,7 @@ struct mtr_ctx {
     unsigned *d_st_bincnt = nullptr; int32_t *d_st_dpbin = nullptr, *d_st_dprank = nullptr, *d_st_binstart = nullptr, *d_st_sorted = nullptr, *d_st_classwave = nullptr;
     DevRecord *d_st_cand = nullptr; int32_t *d_st_flag = nullptr; unsigned long long *d_st_scalars = nullptr;
     int32_t *d_st_wv = nullptr, *d_st_res = nullptr; int4 *d_st_items = nullptr, *d_st_cont = nullptr; int64_t *d_st_rev = nullptr;
+    int8_t *d_st_ipass = nullptr; int32_t *d_st_plist0 = nullptr, *d_st_plist1 = nullptr, *d_st_re2 = nullptr;      // the chain's two passes
     // cost-ordered queue of the per-read unit kernel
     unsigned *d_lpt_count = nullptr; int32_t *d_lpt_start = nullptr, *d_lpt_bin = nullptr, *d_lpt_rank = nullptr, *d_lpt_order = nullptr;
     std::vector<std::pair<void *, size_t>> caps;       // (address of the pointer member, bytes allocated)
@@ -257,6 +260,7 @@ static void release_batch_buffers(mtr_ctx *ctx)
     dfree(ctx->d_tail); dfree(ctx->d_tail_off);
     dfree(ctx->d_st_arena); dfree(ctx->d_st_kc); dfree(ctx->d_st_dp); dfree(ctx->d_st_bincnt); dfree(ctx->d_st_dpbin); dfree(ctx->d_st_dprank);
     dfree(ctx->d_st_binstart); dfree(ctx->d_st_sorted); dfree(ctx->d_st_classwave); dfree(ctx->d_st_cand); dfree(ctx->d_st_flag); dfree(ctx->d_st_scalars); dfree(ctx->d_st_wv); dfree(ctx->d_st_res); dfree(ctx->d_st_items); dfree(ctx->d_st_cont); dfree(ctx->d_st_rev);
+    dfree(ctx->d_st_ipass); dfree(ctx->d_st_plist0); dfree(ctx->d_st_plist1); dfree(ctx->d_st_re2);
     dfree(ctx->d_lpt_count); dfree(ctx->d_lpt_start); dfree(ctx->d_lpt_bin); dfree(ctx->d_lpt_rank); dfree(ctx->d_lpt_order);
     dfree(ctx->d_wire_bytes); dfree(ctx->d_wire_off); dfree(ctx->d_wire);
     dfree(ctx->d_al_i32); dfree(ctx->d_al_len); dfree(ctx->d_al_ends); dfree(ctx->d_al_units); dfree(ctx->d_al_ops); dfree(ctx->d_al_off);
@@ -298,7 +302,7 @@ extern "C" mtr_status mtr_create(int device, int manhattan, float min_match_rati
     DBG("mtr_create: runtime up, device selected");
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 4; i++) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
-    for (int i = 2; ok && i < MTR_N_KERNEL_TIMES; i++) ok = hipEventCreate(&ctx->ev_ph[i]) == hipSuccess;
+    for (int i = 2; ok && i < MTR_N_KERNEL_TIMES; i++) ok = hipEventCreate(&ctx->ev_ph[i]) == hipSuccess && hipEventCreate(&ctx->ev_ph2[i]) == hipSuccess;
     ok = ok && hipMalloc(&ctx->d_status, sizeof(int32_t)) == hipSuccess;
     ok = ok && hipMalloc(&ctx->d_work, sizeof(unsigned)) == hipSuccess;
     ok = ok && hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * CNT_N) == hipSuccess;
@@ -335,7 +339,7 @@ extern "C" void mtr_destroy(mtr_ctx *ctx)
     dfree(ctx->d_status); dfree(ctx->d_work); dfree(ctx->d_counters); dfree(ctx->d_scratch);
     dfree(ctx->d_trace); dfree(ctx->d_trace_n); dfree(ctx->d_fail_read);
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
-    for (int i = 0; i < MTR_N_KERNEL_TIMES; i++) if (ctx->ev_ph[i]) (void)hipEventDestroy(ctx->ev_ph[i]);
+    for (int i = 0; i < MTR_N_KERNEL_TIMES; i++) { if (ctx->ev_ph[i]) (void)hipEventDestroy(ctx->ev_ph[i]); if (ctx->ev_ph2[i]) (void)hipEventDestroy(ctx->ev_ph2[i]); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -663,6 +667,18 @@ static int staged_quad_min(int64_t bases)
     if (e) { const long v = atol(e); return (int)(v < 0 ? 0 : (v > 0x7fffffff ? 0x7fffffff : v)); }
     return bases >= 8000000 ? 1024 : 0;
 }
+static int staged_two_pass(int64_t bases, int n_reads)
+{   // the chain in two passes - the ranges of wide windows first, then what their records leave (k3_staged.hip.inc): 1 = the wide ranges that no earlier
+    // wide range contains first, 2 = every wide range first.  MTR_TWO_PASS forces it.
+    // [measured, MI355X, host call on one resident batch, ms: one pass / two passes / every wide range first]  10 000 reads of 2 kb 53.6 / 61.4 / 56.2
+    // (pipelined over two contexts 46.7 / 47.6 / 47.0 a step); 20 000 config-4 reads 82.0 / 91.6 / 84.1; 1 000 config-2 reads 8.4 / 9.5 / 9.5; one 2 kb
+    // read 2.4 / 4.0 / 2.5; 100 reads of 42 kb 120.7 / 127.4 / 123.3; 600 reads of 42 kb 437.9 / 404.5 / 434.1.  Two passes search what the reference
+    // searches (+ 0.4 %) instead of 1.43 x (2 kb reads) or 5.9 x (42 kb reads) that, with 24 % / 80 % fewer k-mer tables - and pay every kernel's tail
+    // twice: they win where the work saved is large and the batch deep enough to hide the tails, i.e. many long reads.
+    const char *e = getenv("MTR_TWO_PASS");
+    if (e) return atoi(e);
+    return (bases >= ((int64_t)16 << 20) && bases / std::max(n_reads, 1) >= 8000) ? 1 : 0;
+}
 static unsigned st_sum(const unsigned long long *cls) { unsigned t = 0; for (int c = 0; c < ST_NCLS; c++) t += (unsigned)cls[c * 32]; return t; }
 static bool use_staged(const mtr_ctx *)
 {   // [measured, round 3] the chain is the faster arrangement for every batch: a single 2 kb read 3.0 against 19 ms, 2 000 reads 19
@@ -741,6 +757,16 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     s.cand = ctx->d_st_cand; s.n_cand = (unsigned *)(sc + 5 * 32); s.cand_flag = ctx->d_st_flag;
     s.n_rev = (unsigned *)(sc + 32 * 32);   // ST_NCLS counters, 256 bytes apart
     s.work = (unsigned *)(sc + 64 * 32);
+    // wide windows first (k3_staged.hip.inc): the chain in two passes.  MTR_TWO_PASS=0 / 1 overrides
+    s.two_pass = staged_two_pass(sumL, n); s.pass = 0; s.defer_w = 160;
+    if (s.two_pass) {
+        ST_ALLOC(ensure_dev(ctx, ctx->d_st_ipass, (size_t)std::max(s.item_cap, 1))); ST_ALLOC(ensure_dev(ctx, ctx->d_st_plist0, (size_t)std::max(s.item_cap, 1) * 4));
+        ST_ALLOC(ensure_dev(ctx, ctx->d_st_plist1, (size_t)std::max(s.item_cap, 1) * 4)); ST_ALLOC(ensure_dev(ctx, ctx->d_st_re2, (size_t)std::max<int64_t>(ctx->total_rcap, 1) * 4));
+    }
+    s.item_pass = ctx->d_st_ipass; s.pass_list[0] = ctx->d_st_plist0; s.pass_list[1] = ctx->d_st_plist1; s.re2 = ctx->d_st_re2;
+    s.n_pass[0] = (unsigned *)(sc + 6 * 32); s.n_pass[1] = (unsigned *)(sc + 7 * 32);
+    ctx->last_two_pass = s.two_pass != 0;
+    if (const char *e = getenv("MTR_TEST_STAGED_FLAGS")) s.test_flags = atoi(e);
     K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
     // few reads: the range finder as one wavefront per (read, pass) over per-READ scratch (launch_k1_parts), as in the
     // range-parallel mode; the unit kernels then take their per-wavefront scratch behind it
@@ -785,65 +811,81 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     hipLaunchKernelGGL(mtr_k_item_table, dim3((unsigned)std::min(n, 4096)), dim3(256), 0, ctx->stream, a, s);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev_ph[2], ctx->stream));       // ranges
-    {   // the walks align nothing: a scratch layout without the cell region, and as many wavefronts as the occupancy allows
-        K2Args aw = a;
-        aw.cells_cap = 256;
-        const size_t pw = k2_layout(ctx->Lmax, aw.cells_cap).total;
-        size_t tw = 0;
-        int ww = pick_waves(ctx, std::max(n * 8, ctx->n_cu * 16), waves_per_cu(), pw, &tw);
-        if (tw > ctx->scratch_bytes) ww = std::min(ww, waves);
-        aw.scratch_per_wave = pw;
-        hipLaunchKernelGGL(mtr_k_walks, dim3((unsigned)capped(ww, 8)), dim3(64), 0, ctx->stream, aw, s);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(mtr_k_walks_k, dim3((unsigned)capped(ww, 32)), dim3(64), 0, ctx->stream, aw, s);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(mtr_k_gather, dim3((unsigned)capped(ctx->n_cu * 32, 64)), dim3(64), 0, ctx->stream, a, s);      // (19 VGPRs, no LDS: eight wavefronts per SIMD hide its loads)
-        HIPCHK(hipGetLastError());
-    }
-    HIPCHK(hipEventRecord(ctx->ev_ph[3], ctx->stream));       // unit search (tables, seeds, walks) + the alignment items
-    if (s.quad_min > 0) {
-        hipLaunchKernelGGL(mtr_k_qbins, dim3(1), dim3(1024), 0, ctx->stream, s, 0);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(mtr_k_qscatter, dim3((unsigned)capped(512, 16384)), dim3(256), 0, ctx->stream, s, ctx->d_status);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(mtr_k_dp2_quads, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
-        HIPCHK(hipGetLastError());
-    }
-    if (s.quad_min <= 0) {                                  // (a big batch: mtr_k_dp2_quads has run them)
-        hipLaunchKernelGGL(mtr_k_dp2_waves, dim3((unsigned)capped(waves_dp, 16)), dim3(64), 0, ctx->stream, a, s);
-        HIPCHK(hipGetLastError());
-    }
-    if (s.quad_min > 0) HIPCHK(hipMemsetAsync(ctx->d_st_bincnt, 0, (size_t)ST_NBINS * 4, ctx->stream));     // the revisions are sorted next
-    HIPCHK(hipEventRecord(ctx->ev_ph[4], ctx->stream));       // two-parameter alignments
-    hipLaunchKernelGGL(mtr_k_select, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ctx->ev_ph[5], ctx->stream));       // selection
-    if (s.quad_min > 0) {
-        // four revisions per wavefront.  First every revision is polished (a work item each), then the revisions of a range whose polished
-        // states are equal are joined and the ones that run are binned (the alignments' sort buffers are free again)
-        {
-            K2Args ap = a;
-            ap.cells_cap = 256;                             // (polish aligns nothing: the scratch layout of the walks)
-            const size_t pw = k2_layout(ctx->Lmax, ap.cells_cap).total;
+    // one pass of the chain, from the walks to the candidate records (two passes: the work lists of the chain start from zero for the second)
+    auto run_pass = [&](int pass) -> mtr_status {
+        hipEvent_t *evp = pass == 0 ? ctx->ev_ph : ctx->ev_ph2;
+        s.pass = pass;
+        {   // the walks align nothing: a scratch layout without the cell region, and as many wavefronts as the occupancy allows
+            K2Args aw = a;
+            aw.cells_cap = 256;
+            const size_t pw = k2_layout(ctx->Lmax, aw.cells_cap).total;
             size_t tw = 0;
-            int wp = pick_waves(ctx, std::max(n * 8, ctx->n_cu * 16), waves_per_cu(), pw, &tw);
-            if (tw > ctx->scratch_bytes) wp = std::min(wp, waves);
-            ap.scratch_per_wave = pw;
-            hipLaunchKernelGGL(mtr_k_polish, dim3((unsigned)capped(wp, 256)), dim3(64), 0, ctx->stream, ap, s);
+            int ww = pick_waves(ctx, std::max(n * 8, ctx->n_cu * 16), waves_per_cu(), pw, &tw);
+            if (tw > ctx->scratch_bytes) ww = std::min(ww, waves);
+            aw.scratch_per_wave = pw;
+            hipLaunchKernelGGL(mtr_k_walks, dim3((unsigned)capped(ww, 8)), dim3(64), 0, ctx->stream, aw, s);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(mtr_k_walks_k, dim3((unsigned)capped(ww, 32)), dim3(64), 0, ctx->stream, aw, s);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(mtr_k_gather, dim3((unsigned)capped(ctx->n_cu * 32, 64)), dim3(64), 0, ctx->stream, a, s);      // (19 VGPRs, no LDS: eight wavefronts per SIMD hide its loads)
             HIPCHK(hipGetLastError());
         }
-        hipLaunchKernelGGL(mtr_k_rev_share, dim3((unsigned)capped(ctx->n_cu * 32, 64)), dim3(64), 0, ctx->stream, a, s);
+        HIPCHK(hipEventRecord(evp[3], ctx->stream));       // unit search (tables, seeds, walks) + the alignment items
+        if (s.quad_min > 0) {
+            hipLaunchKernelGGL(mtr_k_qbins, dim3(1), dim3(1024), 0, ctx->stream, s, 0);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(mtr_k_qscatter, dim3((unsigned)capped(512, 16384)), dim3(256), 0, ctx->stream, s, ctx->d_status);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(mtr_k_dp2_quads, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
+            HIPCHK(hipGetLastError());
+        }
+        if (s.quad_min <= 0) {                                  // (a big batch: mtr_k_dp2_quads has run them)
+            hipLaunchKernelGGL(mtr_k_dp2_waves, dim3((unsigned)capped(waves_dp, 16)), dim3(64), 0, ctx->stream, a, s);
+            HIPCHK(hipGetLastError());
+        }
+        if (s.quad_min > 0) HIPCHK(hipMemsetAsync(ctx->d_st_bincnt, 0, (size_t)ST_NBINS * 4, ctx->stream));     // the revisions are sorted next
+        HIPCHK(hipEventRecord(evp[4], ctx->stream));       // two-parameter alignments
+        hipLaunchKernelGGL(mtr_k_select, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(mtr_k_qbins, dim3(1), dim3(1024), 0, ctx->stream, s, 1);
+        HIPCHK(hipEventRecord(evp[5], ctx->stream));       // selection
+        if (s.quad_min > 0) {
+            // four revisions per wavefront.  First every revision is polished (a work item each), then the revisions of a range whose polished
+            // states are equal are joined and the ones that run are binned (the alignments' sort buffers are free again)
+            {
+                K2Args ap = a;
+                ap.cells_cap = 256;                             // (polish aligns nothing: the scratch layout of the walks)
+                const size_t pw = k2_layout(ctx->Lmax, ap.cells_cap).total;
+                size_t tw = 0;
+                int wp = pick_waves(ctx, std::max(n * 8, ctx->n_cu * 16), waves_per_cu(), pw, &tw);
+                if (tw > ctx->scratch_bytes) wp = std::min(wp, waves);
+                ap.scratch_per_wave = pw;
+                hipLaunchKernelGGL(mtr_k_polish, dim3((unsigned)capped(wp, 256)), dim3(64), 0, ctx->stream, ap, s);
+                HIPCHK(hipGetLastError());
+            }
+            hipLaunchKernelGGL(mtr_k_rev_share, dim3((unsigned)capped(ctx->n_cu * 32, 64)), dim3(64), 0, ctx->stream, a, s);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(mtr_k_qbins, dim3(1), dim3(1024), 0, ctx->stream, s, 1);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(mtr_k_rscatter, dim3((unsigned)capped(512, 16384)), dim3(256), 0, ctx->stream, s);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(mtr_k_revise_quads, dim3((unsigned)capped(waves, 256)), dim3(64), 0, ctx->stream, a, s);
+        } else hipLaunchKernelGGL(mtr_k_revise, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(mtr_k_rscatter, dim3((unsigned)capped(512, 16384)), dim3(256), 0, ctx->stream, s);
+        HIPCHK(hipEventRecord(evp[6], ctx->stream));       // revisions
+        hipLaunchKernelGGL(mtr_k_finish, dim3((unsigned)capped(ctx->n_cu * 32, 64)), dim3(64), 0, ctx->stream, a, s);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(mtr_k_revise_quads, dim3((unsigned)capped(waves, 256)), dim3(64), 0, ctx->stream, a, s);
-    } else hipLaunchKernelGGL(mtr_k_revise, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ctx->ev_ph[6], ctx->stream));       // revisions
-    hipLaunchKernelGGL(mtr_k_finish, dim3((unsigned)capped(ctx->n_cu * 32, 64)), dim3(64), 0, ctx->stream, a, s);
-    HIPCHK(hipGetLastError());
+        return MTR_OK;
+    };
+    { mtr_status ps = run_pass(0); if (ps != MTR_OK) return ps; }
+    if (s.two_pass) {
+        hipLaunchKernelGGL(mtr_k_pass_mark, dim3((unsigned)std::min(n, 65535)), dim3(64), 0, ctx->stream, a, s);
+        HIPCHK(hipGetLastError());
+        // the lists of the chain start again: everything behind the scalars that live across the passes (items, candidates, the two pass lists)
+        HIPCHK(hipMemsetAsync((uint8_t *)ctx->d_st_scalars + 8 * 256, 0, st_scalar_bytes - 8 * 256, ctx->stream));
+        if (s.quad_min > 0) HIPCHK(hipMemsetAsync(ctx->d_st_bincnt, 0, (size_t)ST_NBINS * 4, ctx->stream));
+        HIPCHK(hipEventRecord(ctx->ev_ph2[2], ctx->stream));
+        { mtr_status ps = run_pass(1); if (ps != MTR_OK) return ps; }
+    }
     ctx->st_cand_cap = s.cand_cap;
     SplitArgs sp{};
     sp.item_off = ctx->d_item_off; sp.cand = ctx->d_st_cand; sp.cand_flag = ctx->d_st_flag;
@@ -915,8 +957,20 @@ extern "C" mtr_status mtr_wait(mtr_ctx *ctx)
     if (ctx->last_staged) {
         hipEvent_t prev = ctx->ev[2];
         for (int p = 2; p < MTR_N_KERNEL_TIMES; p++) {
+            // (two passes: the first pass ends with its revisions, then mtr_k_finish, the mark pass and the second pass's phases 3..6, whose
+            //  durations are added to the first's; the last phase = finish + mark + finish + replay)
             hipEvent_t cur = p == MTR_N_KERNEL_TIMES - 1 ? ctx->ev[3] : ctx->ev_ph[p];
+            if (ctx->last_two_pass && p == MTR_N_KERNEL_TIMES - 1) {
+                float m1 = 0, m2 = 0;
+                HIPCHK(hipEventElapsedTime(&m1, ctx->ev_ph[6], ctx->ev_ph2[2])); HIPCHK(hipEventElapsedTime(&m2, ctx->ev_ph2[6], ctx->ev[3]));
+                ctx->kt[p].ms = m1 + m2; ctx->kt[p].launches = 2;
+                break;
+            }
             HIPCHK(hipEventElapsedTime(&ms, prev, cur)); ctx->kt[p].ms = ms; ctx->kt[p].launches = 1;
+            if (ctx->last_two_pass && p >= 3) {
+                float m2 = 0;
+                HIPCHK(hipEventElapsedTime(&m2, ctx->ev_ph2[p - 1], ctx->ev_ph2[p])); ctx->kt[p].ms += m2; ctx->kt[p].launches = 2;
+            }
             prev = cur;
         }
     }

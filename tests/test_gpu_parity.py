@@ -268,6 +268,12 @@ MODES = {"per_read": {"MTR_STAGED": "0"},
          # the lists of a big batch in 64 sub-lists with a counter each (k3_staged.hip.inc), forced on a small one
          "staged_sublists": {"MTR_STAGED": "1", "MTR_QUAD_MIN": "0", "MTR_TEST_STAGED_CAPS": "nsub=64"},
          "staged_sublists_quads": {"MTR_STAGED": "1", "MTR_QUAD_MIN": "1", "MTR_TEST_STAGED_CAPS": "nsub=64"},
+         # the chain in TWO passes (the ranges of wide windows first, then what their records leave; the default for deep batches of long reads),
+         # and with every wide range in the first pass
+         "staged_two_pass": {"MTR_STAGED": "1", "MTR_TWO_PASS": "1"}, "staged_two_pass_quads": {"MTR_STAGED": "1", "MTR_TWO_PASS": "1", "MTR_QUAD_MIN": "1"},
+         "staged_two_pass_all_wide_first": {"MTR_STAGED": "1", "MTR_TWO_PASS": "2", "MTR_TEST_STAGED_CAPS": "nsub=64"},
+         # two passes whose mark pass lists nothing: the replay reaches ranges nobody searched and sends those reads to the per-read kernel
+         "staged_sent_back": {"MTR_STAGED": "1", "MTR_TWO_PASS": "1", "MTR_TEST_STAGED_FLAGS": "1"},
          "staged_overflow_sublist": {"MTR_STAGED": "1", "MTR_TEST_STAGED_CAPS": "nsub=64,kc=640"},       # 10 blocks per sub-list
          "staged_overflow_arena": {"MTR_STAGED": "1", "MTR_TEST_STAGED_CAPS": "arena=200000"},
          "staged_overflow_kc": {"MTR_STAGED": "1", "MTR_TEST_STAGED_CAPS": "kc=40"},
@@ -294,6 +300,13 @@ def test_kernel_modes_match_the_oracle(monkeypatch, oracle, mode):
     got = e.process(reads)
     if mode.startswith("staged"):
         assert e.last_mode() == ("per-read kernel" if "overflow" in mode else "staged chain")
+        cnt = e.counters()
+        if mode == "staged_sent_back":
+            assert cnt["reads_sent_back"] > 20
+        elif "overflow" not in mode:
+            assert cnt["reads_sent_back"] == 0
+            if "two_pass" in mode:
+                assert cnt["ranges_searched"] < 1.1 * cnt["ranges_executed"], (cnt["ranges_searched"], cnt["ranges_executed"])      # what the reference's loop reaches, + a few per cent
     for i, codes in enumerate(reads):
         want = oracle.process(codes)
         assert [tuple(r) for r in got[i]] == want, _diff_msg(i, want, [tuple(r) for r in got[i]])
@@ -349,14 +362,14 @@ def test_the_chain_runs_every_batch_and_overlapping_launches_agree(monkeypatch):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("mode", ["per_read", "staged", "staged_quads"])
+@pytest.mark.parametrize("mode", ["per_read", "staged", "staged_quads", "staged_two_pass", "staged_two_pass_quads"])
 def test_kernel_modes_golden(monkeypatch, mode):
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)
     engines = {"default": mtr_amd.Engine(manhattan=True), "p": mtr_amd.Engine(manhattan=False)}
     checked = 0
     for name, mode in gu.cases():
-        if name not in ("2_5_10_20_set", "10_50", "synth_2k", "edge", "3_5"):
+        if name not in ("2_5_10_20_set", "10_50", "synth_2k", "edge", "3_5", "synth_c3"):
             continue
         reads = gu.read_fasta(gu.input_path(name))
         cap = gu.capture_by_read(name, mode)
@@ -420,7 +433,7 @@ def _file_order_case():
     return reads
 
 
-@pytest.mark.parametrize("manhattan,split", [(True, "per_read"), (False, "per_read"), (True, "staged"), (False, "staged"), (True, "staged_quads")])
+@pytest.mark.parametrize("manhattan,split", [(True, "per_read"), (False, "per_read"), (True, "staged"), (False, "staged"), (True, "staged_quads"), (True, "staged_two_pass")])
 def test_file_order_mode_matches_reference_behaviour_on_a_file(monkeypatch, manhattan, split):
     """mtr_upload_batch_in_file: the records equal the oracle's file-order mode (pinned to the reference run on whole
     files, tests/test_oracle_golden.py) whatever the batch boundaries, in both kernel modes; and they differ from the

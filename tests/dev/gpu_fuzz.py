@@ -76,8 +76,10 @@ def main():
             t_or = time.time() - t0
             # "batches of 100": the range finder of few reads (one wavefront per (read, pass, segment), the passes of a read as a
             # pipeline of 16 wavefronts, mtr_k1_finish_pipe) instead of one wavefront per read
-            modes = {"per-read": dict(MTR_STAGED="0", MTR_QUAD_MIN="0"), "staged": dict(MTR_STAGED="1", MTR_QUAD_MIN="0"),
-                     "staged+quads": dict(MTR_STAGED="1", MTR_QUAD_MIN="1"), "staged, batches of 100": dict(MTR_STAGED="1", MTR_QUAD_MIN="0")}
+            modes = {"per-read": dict(MTR_STAGED="0", MTR_QUAD_MIN="0", MTR_TWO_PASS="0"), "staged": dict(MTR_STAGED="1", MTR_QUAD_MIN="0", MTR_TWO_PASS="0"),
+                     "staged+quads": dict(MTR_STAGED="1", MTR_QUAD_MIN="1", MTR_TWO_PASS="0"), "staged, batches of 100": dict(MTR_STAGED="1", MTR_QUAD_MIN="0", MTR_TWO_PASS="0"),
+                     "staged+quads, two passes": dict(MTR_STAGED="1", MTR_QUAD_MIN="1", MTR_TWO_PASS="1"),
+                     "staged, two passes, batches of 100": dict(MTR_STAGED="1", MTR_QUAD_MIN="0", MTR_TWO_PASS="1")}
             for split in modes:
                 os.environ.update(modes[split])
                 eng = mtr_amd.Engine(manhattan=manhattan)

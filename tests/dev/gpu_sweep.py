@@ -30,9 +30,10 @@ def main():
             t0 = time.time()
             want = [w for ch in pool.map(oracle_chunk, [(manhattan, c) for c in chunks]) for w in ch]
             t_or = time.time() - t0
-            modes = {"per-read": dict(MTR_STAGED="0", MTR_QUAD_MIN="0"), "staged": dict(MTR_STAGED="1", MTR_QUAD_MIN="0"),
-                     "staged+quads": dict(MTR_STAGED="1", MTR_QUAD_MIN="1")}
-            for split in (("per-read", "staged+quads") if len(reads) > 20000 else tuple(modes)):
+            modes = {"per-read": dict(MTR_STAGED="0", MTR_QUAD_MIN="0", MTR_TWO_PASS="0"), "staged": dict(MTR_STAGED="1", MTR_QUAD_MIN="0", MTR_TWO_PASS="0"),
+                     "staged+quads": dict(MTR_STAGED="1", MTR_QUAD_MIN="1", MTR_TWO_PASS="0"),
+                     "staged+quads, two passes": dict(MTR_STAGED="1", MTR_QUAD_MIN="1", MTR_TWO_PASS="1")}
+            for split in (("per-read", "staged+quads", "staged+quads, two passes") if len(reads) > 20000 else tuple(modes)):
                 os.environ.update(modes[split])
                 eng = mtr_amd.Engine(manhattan=manhattan)
                 t0 = time.time(); got = eng.process(reads); t_gpu = time.time() - t0

@@ -20,8 +20,8 @@ wire-form tables go device-to-device to rank 0 over RCCL (mtr_export_packed_devi
 config 4 — one set of 100 000 mixed-unit reads, contiguous blocks balanced by sum of lengths; rank 0 checks the sha256 of
 the gathered stream against the known answer of the CPU oracle (tests/golden/c4_100k_wire.json) and reports ranks_seen.
 
-roofline: a launch is the staged chain (k3_staged.hip.inc: ranges -> unit search -> alignments -> selection -> revisions -> replay,
-one stream, no host round trip); its duration and the durations of its phases are measured with HIP events on the launch stream
+roofline: a launch is the staged chain (k3_staged.hip.inc: ranges -> [unit search -> alignments -> selection -> revisions] for the ranges of wide
+windows, then for the ranges their records leave -> replay, one stream, no host round trip); its duration and the durations of its phases are measured with HIP events on the launch stream
 inside the timed region (mtr_get_kernel_times), the dominant phases are the wrap-around DP kernels mtr_k_dp2_quads (alignments) and
 mtr_k_revise_quads (revisions).  The path is bound by VALU instruction issue (row-serial integer max-plus recurrence),
 so `bound` is "valu-issue": `achieved` = the REFERENCE's DP cell updates of one launch x 7 integer operations / the
@@ -446,8 +446,9 @@ def main():
                             "alignments_bytes": cnt["qpass_bytes_dp2"], "revisions_bytes": cnt["qpass_bytes_rev"]},
             "reference_work_per_launch": {k: ref_cnt[k] for k in ("dp_calls", "dp_cells", "revise_dp_calls", "revise_dp_cells", "memo_hits", "memo_cells", "ranges_executed", "records")},
             "roofline": {"bound": "valu-issue",
-                         "kernel": "one launch = the staged chain (mtr_k1_ranges, mtr_k_walks, mtr_k_walks_k, mtr_k_gather, mtr_k_dp2_quads, mtr_k_dp2_waves, "
-                                   "mtr_k_select, mtr_k_revise_quads, mtr_k_finish, mtr_k_replay); dominant kernels: mtr_k_revise_quads and mtr_k_dp2_quads (kernels_ms.phases)",
+                         "kernel": "one launch = the staged chain (mtr_k1_ranges; then per pass - the ranges of wide windows first, then what their records leave - mtr_k_walks, "
+                                   "mtr_k_walks_k, mtr_k_gather, mtr_k_dp2_quads, mtr_k_select, mtr_k_polish, mtr_k_rev_share, mtr_k_revise_quads, mtr_k_finish; mtr_k_pass_mark between the "
+                                   "passes, mtr_k_replay at the end); dominant kernels: mtr_k_revise_quads and mtr_k_dp2_quads (kernels_ms.phases)",
                          "achieved": valu_ops / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s",
                          "frac": valu_ops / VALU_PEAK_LANE_OPS,
                          "frac_by_step": cells * OPS_PER_CELL / step_s / VALU_PEAK_LANE_OPS,

@@ -674,10 +674,15 @@ static int staged_two_pass(int64_t bases, int n_reads)
     // (pipelined over two contexts 46.7 / 47.6 / 47.0 a step); 20 000 config-4 reads 82.0 / 91.6 / 84.1; 1 000 config-2 reads 8.4 / 9.5 / 9.5; one 2 kb
     // read 2.4 / 4.0 / 2.5; 100 reads of 42 kb 120.7 / 127.4 / 123.3; 600 reads of 42 kb 437.9 / 404.5 / 434.1.  Two passes search what the reference
     // searches (+ 0.4 %) instead of 1.43 x (2 kb reads) or 5.9 x (42 kb reads) that, with 24 % / 80 % fewer k-mer tables - and pay every kernel's tail
-    // twice: they win where the work saved is large and the batch deep enough to hide the tails, i.e. many long reads.
+    // twice: they win where the work saved is large and the batch deep enough to hide the tails, i.e. many long reads (1).  With EVERY wide range in
+    // the first pass (2) the second pass has nothing long in it: pipelined over two contexts it costs nothing (final build, 20 steps, twice: 44.32 /
+    // 44.35 ms a step in one pass, 44.42 / 44.32 with every wide range first, 45.30 / 45.22 in mode 1) while a lone launch takes 53.7 instead of
+    // 51.8 ms.  So: batches too small for the four-per-wavefront passes (< 8 M bases, where a launch's own latency is what counts) keep one pass;
+    // deep batches of long reads take mode 1; every other big batch mode 2 - the chain then searches what the reference searches.
     const char *e = getenv("MTR_TWO_PASS");
     if (e) return atoi(e);
-    return (bases >= ((int64_t)16 << 20) && bases / std::max(n_reads, 1) >= 8000) ? 1 : 0;
+    if (bases >= ((int64_t)16 << 20) && bases / std::max(n_reads, 1) >= 8000) return 1;
+    return bases >= 8000000 ? 2 : 0;
 }
 static unsigned st_sum(const unsigned long long *cls) { unsigned t = 0; for (int c = 0; c < ST_NCLS; c++) t += (unsigned)cls[c * 32]; return t; }
 static bool use_staged(const mtr_ctx *)
@@ -866,7 +871,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(mtr_k_qbins, dim3(1), dim3(1024), 0, ctx->stream, s, 1);
             HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL(mtr_k_rscatter, dim3((unsigned)capped(512, 16384)), dim3(256), 0, ctx->stream, s);
+            hipLaunchKernelGGL(mtr_k_rscatter, dim3((unsigned)capped(512, 16384)), dim3(256), 0, ctx->stream, s, ctx->d_status);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(mtr_k_revise_quads, dim3((unsigned)capped(waves, 256)), dim3(64), 0, ctx->stream, a, s);
         } else hipLaunchKernelGGL(mtr_k_revise, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);

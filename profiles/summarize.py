@@ -81,11 +81,13 @@ def main():
     groups = {g: per_kernel(counter_rows(os.path.join(out, g))) for g in ("fetch", "write", "sq1", "sq2", "lds")}
     s["counters_per_launch"] = groups
     chain = [k for k in dur_ms if not k.startswith(NOT_CHAIN)]
-    dom = max(chain, key=dur_ms.get) if chain else None
+    calls0 = {r["Name"].split("(")[0].replace("void ", ""): int(r["Calls"]) for r in s.get("kernel_stats", [])}
+    dom = max(chain, key=lambda k: dur_ms[k] * calls0.get(k, 1)) if chain else None      # by time per LAUNCH (the two-pass chain runs most kernels twice)
     s["dominant_kernel"] = dom
     if dom:
-        def launches(grp):            # launches of the chain seen by a counter pass = dispatches of a kernel that runs once per launch
-            return max(1, int(groups.get(grp, {}).get("mtr_k_gather", {}).get("_launches", 1)))
+        def launches(grp):            # launches of the chain seen by a counter pass = dispatches of a kernel that runs ONCE per launch (the two-pass chain runs most kernels twice)
+            g = groups.get(grp, {})
+            return max(1, int((g.get("mtr_k_replay") or g.get("mtr_k_items") or g.get("mtr_k_gather") or {}).get("_launches", 1)))
 
         def total(grp, c):            # per launch of the chain: sum over its kernels of (mean per dispatch x dispatches) / launches
             t, seen = 0.0, False
@@ -97,7 +99,7 @@ def main():
 
         table = {}
         calls = {r["Name"].split("(")[0].replace("void ", ""): int(r["Calls"]) for r in s.get("kernel_stats", [])}
-        n_launch_trace = max(1, calls.get("mtr_k_gather", 1))
+        n_launch_trace = max(1, calls.get("mtr_k_replay", calls.get("mtr_k_items", calls.get("mtr_k_gather", 1))))
         for k in sorted(chain, key=lambda k: -dur_ms[k] * calls.get(k, 1)):
             row = {"ms_per_launch": dur_ms[k] * calls.get(k, 1) / n_launch_trace}
             for grp, c, key, mul in (("sq2", "SQ_INSTS_VALU", "valu", 1.0), ("sq2", "SQ_INSTS_SALU", "salu", 1.0), ("fetch", "FETCH_SIZE", "fetch_bytes", 1024.0),

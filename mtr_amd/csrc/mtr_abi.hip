@@ -910,23 +910,38 @@ static mtr_status resolve_overflow(mtr_ctx *ctx)
     const int n = ctx->n_reads;
     std::vector<int32_t> cnt((size_t)n);
     HIPCHK(copy_sync(ctx, cnt.data(), ctx->d_reccount, (size_t)n * 4, hipMemcpyDeviceToHost));
+    // A read the staged chain sent back (mtr_k_replay met a range the second pass had not searched) carries a mark instead of
+    // a count: it most likely fits its max_rec slots, so it is given max_rec + 1 at first rather than the mark's worth of memory
+    const int sent_back_mark = 4 * ctx->max_rec + 4096;
     ctx->ovf_reads.clear(); ctx->ovf_cap = 0;
-    for (int i = 0; i < n; i++) if (cnt[(size_t)i] > ctx->max_rec) { ctx->ovf_reads.push_back(i); ctx->ovf_cap = std::max(ctx->ovf_cap, (int)cnt[(size_t)i]); }
+    for (int i = 0; i < n; i++) if (cnt[(size_t)i] > ctx->max_rec) {
+        ctx->ovf_reads.push_back(i);
+        ctx->ovf_cap = std::max(ctx->ovf_cap, cnt[(size_t)i] == sent_back_mark ? ctx->max_rec + 1 : (int)cnt[(size_t)i]);
+    }
     if (ctx->ovf_reads.empty()) return MTR_OK;
     const size_t m = ctx->ovf_reads.size();
-    DBG("resolve_overflow: %zu reads found more than %d records (max %d): running them again", m, ctx->max_rec, ctx->ovf_cap);
     std::vector<int64_t> base((size_t)n, 0);
-    for (size_t k = 0; k < m; k++) base[(size_t)ctx->ovf_reads[k]] = (int64_t)k * ctx->ovf_cap;
-    HIPCHK(ensure_dev(ctx, ctx->d_ovf_records, m * (size_t)ctx->ovf_cap * sizeof(DevRecord)));
     HIPCHK(ensure_dev(ctx, ctx->d_rec_base, (size_t)n * 8)); HIPCHK(ensure_dev(ctx, ctx->d_ovf_order, m * 4));
-    HIPCHK(hipMemcpyAsync(ctx->d_rec_base, base.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_ovf_order, ctx->ovf_reads.data(), m * 4, hipMemcpyHostToDevice, ctx->stream));
-    ctx->sub_active = true;
-    mtr_status s = launch_reads(ctx);                   // one wavefront per read; events ev[2..3] are re-recorded, the
-    ctx->sub_active = false;                            // kernel time reported stays the first run's (read before)
-    if (s != MTR_OK) return s;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return check_status(ctx);
+    for (int attempt = 0; ; attempt++) {                // the run again reports true counts: once more only if one of them is larger
+        DBG("resolve_overflow: %zu reads found more than %d records or were sent back: running them again with room for %d each", m, ctx->max_rec, ctx->ovf_cap);
+        for (size_t k = 0; k < m; k++) base[(size_t)ctx->ovf_reads[k]] = (int64_t)k * ctx->ovf_cap;
+        HIPCHK(ensure_dev(ctx, ctx->d_ovf_records, m * (size_t)ctx->ovf_cap * sizeof(DevRecord)));
+        HIPCHK(hipMemcpyAsync(ctx->d_rec_base, base.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        ctx->sub_active = true;
+        mtr_status s = launch_reads(ctx);               // one wavefront per read; events ev[2..3] are re-recorded, the
+        ctx->sub_active = false;                        // kernel time reported stays the first run's (read before)
+        if (s != MTR_OK) return s;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        s = check_status(ctx);
+        if (s != MTR_OK) return s;
+        HIPCHK(copy_sync(ctx, cnt.data(), ctx->d_reccount, (size_t)n * 4, hipMemcpyDeviceToHost));
+        int need = 0;
+        for (size_t k = 0; k < m; k++) need = std::max(need, (int)cnt[(size_t)ctx->ovf_reads[k]]);
+        if (need <= ctx->ovf_cap) return MTR_OK;
+        if (attempt >= 2) return MTR_ERR_OVERFLOW;       // counts of the same reads cannot keep growing
+        ctx->ovf_cap = need;
+    }
 }
 
 extern "C" mtr_status mtr_run_resident_async(mtr_ctx *ctx)

@@ -401,6 +401,29 @@ def test_more_records_than_slots(eng, oracle):
         assert [tuple(r) for r in got[i]] == want[i], _diff_msg(i, want[i], [tuple(r) for r in got[i]])
 
 
+def test_a_read_sent_back_that_also_has_more_records_than_slots(monkeypatch, oracle):
+    """A read the staged chain sends back to the per-read kernel is first given max_rec + 1 slots (the mark it carries says nothing
+    about its count); when its true count is larger, resolve_overflow runs it once more with room for all of them."""
+    for k, v in MODES["staged_sent_back"].items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.RandomState(32)
+    parts = []
+    for _ in range(70):
+        u = rng.randint(0, 4, size=int(rng.randint(3, 9))).astype(np.uint8)
+        parts.append(np.tile(u, 9)); parts.append(rng.randint(0, 4, size=6).astype(np.uint8))
+    crowded = np.concatenate(parts)
+    reads = [c for _, c in synth.make_reads("headline2k", 20, 79)] + [crowded] + [c for _, c in synth.make_reads("c2", 10, 80)]
+    e = mtr_amd.Engine()
+    got = e.process(reads)
+    assert e.last_mode() == "staged chain" and e.counters()["reads_sent_back"] > 5
+    want = [oracle.process(c) for c in reads]
+    slots = 16 + max(len(r) for r in reads) // 100
+    assert len(want[20]) > slots + 1, f"the crowded read should overflow its {slots} slots, it reports {len(want[20])}"
+    for i in range(len(reads)):
+        assert [tuple(r) for r in got[i]] == want[i], _diff_msg(i, want[i], [tuple(r) for r in got[i]])
+    e.close()
+
+
 def _oracle_chunk(reads):
     from tests.oracle_binding import Oracle
     o = Oracle()

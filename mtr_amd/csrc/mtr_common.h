@@ -129,7 +129,7 @@ struct K2Layout {
     size_t ckeys, cslots;          // int32 [gcap / 2] each: the keys of such a table once more, compact, and their slots (the look-ahead scans these)
     size_t ties;                   // int32 [2][1024] tie lists of the look-ahead
     size_t memo_unit, memo_res;    // DP memo of the current range: uint8 [K2_MEMO_N][512] units, int32 [K2_MEMO_N][16] results
-    size_t step_cache;             // int32 [2][K2_STEP_CACHE][2]: node -> next node of the walks' general look-ahead steps, per direction
+    size_t step_cache;             // int32 [2][K2_STEP_CACHE][4]: node, next node, number of the table the entry is for, 0 - the walks' general look-ahead steps, per direction
     size_t rmemo_key, rmemo_kunit, rmemo_val, rmemo_vunit;   // revision memo: int32 [N][16] + uint8 [N][512] in, int32 [N][16] + uint8 [N][1024] out
     size_t total;
     size_t cells; unsigned gcap;
@@ -164,7 +164,7 @@ static inline __host__ __device__ K2Layout k2_layout(int Lmax, long long cells_c
     y.ties = o; o = mtrc_align(o + 2 * MTRC_MAX_TIEBREAKS * 4, 16);
     y.memo_unit = o; o = mtrc_align(o + (size_t)K2_MEMO_N * K2_MEMO_UNIT, 16);
     y.memo_res = o; o = mtrc_align(o + (size_t)K2_MEMO_N * 16 * 4, 16);
-    y.step_cache = o; o = mtrc_align(o + (size_t)2 * K2_STEP_CACHE * 2 * 4, 16);
+    y.step_cache = o; o = mtrc_align(o + (size_t)2 * K2_STEP_CACHE * 4 * 4, 16);
     y.rmemo_key = o; o = mtrc_align(o + (size_t)K2_RMEMO_N * 16 * 4, 16);
     y.rmemo_kunit = o; o = mtrc_align(o + (size_t)K2_RMEMO_N * K2_MEMO_UNIT, 16);
     y.rmemo_val = o; o = mtrc_align(o + (size_t)K2_RMEMO_N * 16 * 4, 16);

@@ -382,8 +382,31 @@ def main():
         drain()
     dt, k2_ms = timed(a.steps, fetch=True)
     dt_kernel = None
+    dt_upload = None
     if world == 1:
         dt_kernel, _ = timed(a.steps, fetch=False)      # round 1's figure: the kernels alone, results left on the device
+        if not a.strong and a.config is None:
+            # the boundary handing over HOST buffers: every step takes a FRESH batch (three different read sets in turn) as concatenated base
+            # codes + offsets + lengths in host memory (mtr_upload_batch: 2-bit packing on the calling thread + the copy to the device), runs
+            # it and fetches its tables; the upload of step s+1 overlaps the kernels of step s (two contexts), as in the host pipeline
+            flats = [mtr_amd._flatten(reads)] + [mtr_amd._flatten([c for _, c in synth.make_reads(WORKLOAD, a.reads, seed=1000 + k)]) for k in range(2)]
+            def with_upload(steps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for s in range(steps):
+                    e = engs[s % 2]
+                    e.upload_flat(*flats[s % 3])
+                    e.run_async()
+                    if s > 0:
+                        engs[(s - 1) % 2].wait(); engs[(s - 1) % 2].fetch_packed_nocopy()
+                engs[(steps - 1) % 2].wait(); engs[(steps - 1) % 2].fetch_packed_nocopy()
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0
+            with_upload(2)
+            dt_upload = with_upload(a.steps)
+            for e in engs[:2]:
+                e.upload(reads)                          # (the legs below expect the headline batch resident,
+            engs[0].run()                                #  and the counters of its last launch)
 
     if rank == 0:
         cnt = eng.counters()
@@ -411,6 +434,53 @@ def main():
         else:
             workload = (f"{WORKLOAD}: {n_local} synthetic Nanopore reads per GPU, unit 100 x 10 copies, 500-base flanks, "
                         f"mean L {np.mean([len(r) for r in reads]):.0f}, error profile sub 1.6/ins 9.0/del 3.8 %")
+        # ---- roofline of the DOMINANT kernel (mtr_k_revise_quads: four revisions per wavefront), by its own duration: HIP events around its launches
+        # on the launch stream (mtr_get_kernel_times id 8), (i) in the warm-up launches, which have the GPU to themselves - the figure
+        # `rocprofv3 --kernel-trace --stats` of a lone launch reproduces (profiles/) and the one `frac` uses -, (ii) in the pipelined timed region,
+        # where a launch shares the chip with its neighbour (reported, not used).  Its algorithmic work: the cells (rows x unit) of the vote DPs and
+        # re-alignments it ran (no padding: what a pass computes beyond them shows as bytes per cell in quad_passes) x 7 integer operations
+        def kavg(ks, name):
+            v = [k[name] for k in ks if name in k]
+            return float(np.mean(v)) if v else None
+        dom = "mtr_k_revise_quads"
+        dom_lone_ms, dom_timed_ms = kavg(sync_k2, "kernel_" + dom), kavg(k2_ms, "kernel_" + dom)
+        dp2_lone_ms = kavg(sync_k2, "kernel_mtr_k_dp2_quads")
+        dom_cells = cnt["qpass_cells_rev"]
+        launch_lone_s = (float(np.mean([k["k2_units"] for k in sync_k2])) / 1e3) if sync_k2 else None
+        computed_cells = cnt["dp_cells"] + cnt["revise_dp_cells"]
+        if dom_lone_ms or dom_timed_ms:
+            dms = dom_lone_ms or dom_timed_ms
+            dom_ops = dom_cells * OPS_PER_CELL / (dms / 1e3)
+            roofline = {"bound": "valu-issue", "kernel": dom,
+                        "achieved": dom_ops / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s", "frac": dom_ops / VALU_PEAK_LANE_OPS,
+                        "duration_ms": dms, "duration_source": ("HIP events around the kernel's launches, warm-up launches that have the GPU to themselves" if dom_lone_ms
+                                                                else "HIP events around the kernel's launches in the timed region (no warm-up launch ran)"),
+                        "duration_ms_in_timed_region": dom_timed_ms,
+                        "cells_per_launch": dom_cells, "ops_per_cell": OPS_PER_CELL,
+                        "cells_note": "cells (rows x unit) of the vote DPs and re-alignments the kernel ran in its four-per-wavefront passes"}
+        else:       # a batch whose chain runs one DP per wavefront (small batches) or the per-read kernel: no kernel of its own to name - the launch
+            roofline = {"bound": "valu-issue", "kernel": "one launch (the chain ran one DP per wavefront: no dominant four-per-wavefront kernel)",
+                        "achieved": valu_ops / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s", "frac": valu_ops / VALU_PEAK_LANE_OPS,
+                        "duration_ms": k2_avg_s * 1e3, "cells_per_launch": cells, "ops_per_cell": OPS_PER_CELL}
+        roofline.update({
+            "second_kernel": ({"kernel": "mtr_k_dp2_quads", "duration_ms": dp2_lone_ms, "cell_pairs_per_launch": cnt["qpass_cells_dp2"],
+                               "frac": 2 * cnt["qpass_cells_dp2"] * OPS_PER_CELL / (dp2_lone_ms / 1e3) / VALU_PEAK_LANE_OPS,
+                               "note": "two-parameter alignments: a cell pair = the cell of both parameter sets, 2 x 7 operations"} if dp2_lone_ms else None),
+            "whole_launch": {"kernel": "the staged chain (mtr_k1_ranges; per pass mtr_k_walks, mtr_k_walks_k, mtr_k_gather, mtr_k_dp2_quads, mtr_k_select, mtr_k_polish, "
+                                       "mtr_k_rev_share, mtr_k_revise_quads, mtr_k_finish; mtr_k_pass_mark between the passes; mtr_k_replay)",
+                             "cells_reference": cells, "cells_computed": computed_cells,
+                             "frac_by_step": cells * OPS_PER_CELL / step_s / VALU_PEAK_LANE_OPS,
+                             "frac_lone_launch": (cells * OPS_PER_CELL / launch_lone_s / VALU_PEAK_LANE_OPS) if launch_lone_s else None,
+                             "frac_computed_cells": computed_cells * OPS_PER_CELL / step_s / VALU_PEAK_LANE_OPS,
+                             "note": "cells_reference = the reference's DP cells of the launch (memo_cells of them answered without a DP); by the driver-visible step, by a "
+                                     "launch that has the GPU to itself, and the cells the kernels computed by the step"},
+            "issue": issue,
+            "hbm": {"achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+                    "frac_by_step": b_alg / step_s / 1e9 / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": b_alg, "spilled": "every DP of the reference is counted as spilled (SURVEY.md 8d's upper figure)"},
+            "traffic": traffic, "traffic_source": prof_tag,
+            "note": "bound by VALU instruction issue: row-serial integer max-plus recurrence; issue = VALU issue utilisation (SQ_INSTS_VALU x 2 cycles / SIMD-cycles "
+                    "of the launch) of the profiled build; traffic = HBM bytes per launch of the whole chain (FETCH_SIZE x 2 + WRITE_SIZE, separate PMC passes)"})
         out = {
             "metric": "reads/sec, 2 kb Nanopore synthetic" if a.config is None else "reads/sec, config 3 (unit 200 x 200 copies, L ~ 42 kb; secondary line)",
             "value": value,
@@ -445,24 +515,18 @@ def main():
                             "revisions_bytes_per_cell": (cnt["qpass_bytes_rev"] / cnt["qpass_cells_rev"]) if cnt["qpass_cells_rev"] else None,
                             "alignments_bytes": cnt["qpass_bytes_dp2"], "revisions_bytes": cnt["qpass_bytes_rev"]},
             "reference_work_per_launch": {k: ref_cnt[k] for k in ("dp_calls", "dp_cells", "revise_dp_calls", "revise_dp_cells", "memo_hits", "memo_cells", "ranges_executed", "records")},
-            "roofline": {"bound": "valu-issue",
-                         "kernel": "one launch = the staged chain (mtr_k1_ranges; then per pass - the ranges of wide windows first, then what their records leave - mtr_k_walks, "
-                                   "mtr_k_walks_k, mtr_k_gather, mtr_k_dp2_quads, mtr_k_select, mtr_k_polish, mtr_k_rev_share, mtr_k_revise_quads, mtr_k_finish; mtr_k_pass_mark between the "
-                                   "passes, mtr_k_replay at the end); dominant kernels: mtr_k_revise_quads and mtr_k_dp2_quads (kernels_ms.phases)",
-                         "achieved": valu_ops / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s",
-                         "frac": valu_ops / VALU_PEAK_LANE_OPS,
-                         "frac_by_step": cells * OPS_PER_CELL / step_s / VALU_PEAK_LANE_OPS,
-                         "cells_per_launch": cells, "ops_per_cell": OPS_PER_CELL,
-                         "issue": issue,
-                         "hbm": {"achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                                 "frac_by_step": b_alg / step_s / 1e9 / HBM_PEAK_GBS,
-                                 "algorithmic_bytes_per_launch": b_alg, "spilled": "every DP of the reference is counted as spilled (SURVEY.md 8d's upper figure)"},
-                         "traffic": traffic, "traffic_source": prof_tag,
-                         "note": "bound by VALU instruction issue: row-serial integer max-plus recurrence; cells = the reference's DP cells, of which memo_cells were "
-                                 "answered without a DP; issue = VALU issue utilisation (SQ_INSTS_VALU x 2 cycles / SIMD-cycles of the launch) of the profiled build"},
+            "roofline": roofline,
         }
+        out["chain_health"] = {"reads_sent_back": cnt["reads_sent_back"], "ok": cnt["reads_sent_back"] == 0,
+                               "note": "reads the two-pass chain had to send back to the per-read kernel (its mark pass missed a range the reference's loop reaches): must be 0"}
+        if cnt["reads_sent_back"] != 0:
+            print(f"bench.py: WARNING: the chain sent {cnt['reads_sent_back']} reads back to the per-read kernel on the default path", file=sys.stderr)
         if world == 1:
             out["value_kernel"] = n_job * a.steps / dt_kernel
+            if dt_upload:
+                out["value_with_upload"] = n_job * a.steps / dt_upload
+                out["value_with_upload_definition"] = ("every step takes a fresh batch as host buffers (base codes, offsets, lengths): 2-bit packing on the calling thread + "
+                                                       "copy to the device (mtr_upload_batch) + kernels + tables fetched to pinned host memory; PCIe-inclusive, never `value`")
             out["boundary"] = {"wire_bytes_per_step": wire_bytes, "record_struct_bytes_per_step": 2560 * cnt["records"],
                                "fetch_cost_ms_per_step": (dt - dt_kernel) / a.steps * 1e3}
         if a.strong and "blobs" in gathered:
@@ -554,12 +618,15 @@ def main():
             engs.clear()
             torch.cuda.empty_cache()
             t0 = time.perf_counter()
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "c3", "--steps", "4", "--warmup", "1", "--cpu-sample", str(min(a.cpu_sample, 6))]
-                               + (["--no-cli"] if a.no_cli else []), capture_output=True, text=True, cwd=ROOT)
             try:
-                sec = json.loads(p.stdout.strip().splitlines()[-1])
-            except Exception:
-                sec = {"error": (p.stderr or p.stdout)[-400:], "returncode": p.returncode}
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "c3", "--steps", "4", "--warmup", "1", "--cpu-sample", str(min(a.cpu_sample, 6))]
+                                   + (["--no-cli"] if a.no_cli else []), capture_output=True, text=True, cwd=ROOT, timeout=420)
+                try:
+                    sec = json.loads(p.stdout.strip().splitlines()[-1])
+                except Exception:
+                    sec = {"error": (p.stderr or p.stdout)[-400:], "returncode": p.returncode}
+            except subprocess.TimeoutExpired as ex:         # a stuck child must not take the driver-run line with it
+                sec = {"error": "timeout after 420 s: " + ((ex.stderr or b"")[-300:].decode(errors="replace") if isinstance(ex.stderr, bytes) else str(ex.stderr or "")[-300:])}
             sec["wall_s"] = time.perf_counter() - t0
             out["secondary"] = {"c3": sec}
         print(json.dumps(out))

@@ -202,7 +202,9 @@ mtr_status mtr_alignments(mtr_ctx *ctx, int32_t n, const int32_t *read_idx, cons
  * launched on.  Ids: 0 = the range kernel when it runs alone (test entry points), 1 = the whole launch; and the phases of the
  * staged chain (launches = 0 for a batch the per-read kernel ran): 2 = candidate ranges, 3 = unit search (k-mer tables, seeds, walks),
  * 4 = two-parameter alignments, 5 = selection, 6 = revisions, 7 = comparison over k + replay of the sequential range loop. */
-#define MTR_N_KERNEL_TIMES 8
+#define MTR_N_KERNEL_TIMES 10   /* 8, 9 (ABI 5): the two dominant kernels of the chain by themselves, launches of both passes summed -
+                                 * 8 = mtr_k_revise_quads (four revisions per wavefront), 9 = mtr_k_dp2_quads (four alignments per wavefront);
+                                 * launches = 0 when the batch ran one DP per wavefront (small batches) or in the per-read kernel */
 typedef struct mtr_kernel_time { float ms; int32_t launches; } mtr_kernel_time;
 mtr_status mtr_get_kernel_times(const mtr_ctx *ctx, mtr_kernel_time *out, int32_t n_kernels);
 

@@ -25,8 +25,10 @@ COUNTER_NAMES = ["dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_d
                  "cyc_slot_copy", "cyc_dp_fwd_rev", "cyc_dp_tb_rev", "cyc_k1_codes", "cyc_k1_passes", "cyc_k1_extract",
                  "cyc_k1_dedup", "cyc_k1_total",
                  "memo_hits", "memo_cells", "tables_skipped", "cyc_tb_refill", "tb_refills", "walk_steps", "walk_slow_steps", "cyc_walk_slow",
-                 "walk_calls", "walk_closed", "cyc_walk_fast", "spare43", "spare44", "spare45", "spare46", "spare47",
-                 "qpass_bytes_dp2", "qpass_cells_dp2", "qpass_bytes_rev", "qpass_cells_rev", "revisions_shared", "reads_sent_back", "ranges_searched", "spare55"]
+                 "walk_calls", "walk_closed", "cyc_walk_fast", "prof43", "prof44", "prof45", "prof46", "prof47",
+                 "qpass_bytes_dp2", "qpass_cells_dp2", "qpass_bytes_rev", "qpass_cells_rev", "revisions_shared", "reads_sent_back", "ranges_searched", "prof55"]
+# prof43..47, prof55: scratch counters of the profiling builds (-DMTR_PROFILE...); what they count depends on the kernel that wrote them
+# (per-read kernel: revisions / unchanged units / accepted rounds; walk kernels: cycles by window width; see the CNT_SPARE* uses in csrc)
 EXPORTS = ["mtr_create", "mtr_destroy", "mtr_last_error", "mtr_abi_version", "mtr_process_batch", "mtr_free_results",
            "mtr_upload_batch", "mtr_run_resident", "mtr_fetch_results", "mtr_get_kernel_times", "mtr_get_counters",
            "mtr_test_ranges", "mtr_test_wrap_dp", "mtr_test_last_mode", "mtr_set_trace", "mtr_get_trace",
@@ -225,6 +227,13 @@ class Engine:
                         "mtr_upload_batch_in_file")
         self.n_reads = len(reads)
 
+    def upload_flat(self, bases: np.ndarray, offs: np.ndarray, lens: np.ndarray):
+        """mtr_upload_batch on host buffers the caller already holds in the boundary's form (concatenated base codes, offsets, lengths):
+        the library packs them to 2 bit/base on the calling thread and copies the image to the device"""
+        self._keep = (bases, offs, lens)
+        self._check(self.lib.mtr_upload_batch(self.h, bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(lens)), "mtr_upload_batch")
+        self.n_reads = len(lens)
+
     def process_in_file(self, reads: Sequence[np.ndarray], file_state: "FileState") -> List[List[Record]]:
         """the next reads of a file under the reference's whole-file behaviour (include/mtr_hip.h, file-order mode)"""
         self.upload(reads, file_state)
@@ -343,12 +352,16 @@ class Engine:
 
     # ---- measurements ------------------------------------------------------------------------------------
     def kernel_times_ms(self):
-        kt = (CKernelTime * 8)()
-        self._check(self.lib.mtr_get_kernel_times(self.h, kt, 8), "mtr_get_kernel_times")
+        kt = (CKernelTime * 10)()
+        self._check(self.lib.mtr_get_kernel_times(self.h, kt, 10), "mtr_get_kernel_times")
         out = {"k1_ranges": float(kt[0].ms), "k2_units": float(kt[1].ms)}
         for i, name in enumerate(("ranges", "unit_search", "alignments", "selection", "revisions", "finish_replay")):
             if kt[2 + i].launches:
                 out["chain_" + name] = float(kt[2 + i].ms)
+        # the two dominant kernels by themselves (HIP events around each launch on the launch stream; both passes of the chain summed)
+        for i, name in enumerate(("mtr_k_revise_quads", "mtr_k_dp2_quads")):
+            if kt[8 + i].launches:
+                out["kernel_" + name] = float(kt[8 + i].ms)
         return out
 
     def counters(self):

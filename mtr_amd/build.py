@@ -48,12 +48,19 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False) -> 
             continue
         cmd = [hipcc(), *FLAGS, *extra, "-o", lib, os.path.join(CSRC, "mtr_abi.hip")]
         running.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=CSRC)))    # (the two builds side by side)
+    failure = None
     for cmd, p in running:
+        if failure is not None:             # one build failed: the other is not left behind writing its library
+            p.kill()
+            p.communicate()
+            continue
         out, err = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError("hipcc failed:\n" + out + err)
-        if verbose:
+            failure = "hipcc failed (" + " ".join(cmd) + "):\n" + out + err
+        elif verbose:
             print(" ".join(cmd))
+    if failure is not None:
+        raise RuntimeError(failure)
     return LIB
 
 

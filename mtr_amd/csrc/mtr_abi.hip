@@ -57,12 +57,15 @@ static void mt_bases(std::vector<uint8_t> &out, size_t n)
     }
 }
 
+#define MTR_N_PHASE_TIMES 8                         // ids 0..7 of mtr_get_kernel_times: the launch and the phases of the chain; 8, 9: the two dominant kernels
 struct mtr_ctx {
     int device = 0, manhattan = 1; float min_ratio = 0.6f;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
-    hipEvent_t ev_ph[MTR_N_KERNEL_TIMES] = {};     // phase boundaries of the staged chain (ev_ph[p] = end of phase p, p = 2..7)
-    hipEvent_t ev_ph2[MTR_N_KERNEL_TIMES] = {};    // the same for the chain's second pass (ev_ph2[2] = its start); last_two_pass: they were recorded
+    hipEvent_t ev_ph[MTR_N_PHASE_TIMES] = {};     // phase boundaries of the staged chain (ev_ph[p] = end of phase p, p = 2..7)
+    hipEvent_t ev_ph2[MTR_N_PHASE_TIMES] = {};
+    bool last_quads = false;                         // the last chain ran its alignments / revisions four per wavefront (ev_dom recorded)
+    hipEvent_t ev_dom[2][2][2] = {};               // [0 = mtr_k_revise_quads, 1 = mtr_k_dp2_quads][pass][start, end]: the two dominant kernels by themselves (ids 8, 9)    // the same for the chain's second pass (ev_ph2[2] = its start); last_two_pass: they were recorded
     bool last_two_pass = false;
     std::string err;
     int n_cu = 256;
@@ -302,7 +305,8 @@ extern "C" mtr_status mtr_create(int device, int manhattan, float min_match_rati
     DBG("mtr_create: runtime up, device selected");
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 4; i++) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
-    for (int i = 2; ok && i < MTR_N_KERNEL_TIMES; i++) ok = hipEventCreate(&ctx->ev_ph[i]) == hipSuccess && hipEventCreate(&ctx->ev_ph2[i]) == hipSuccess;
+    for (int i = 2; ok && i < MTR_N_PHASE_TIMES; i++) ok = hipEventCreate(&ctx->ev_ph[i]) == hipSuccess && hipEventCreate(&ctx->ev_ph2[i]) == hipSuccess;
+    for (int i = 0; ok && i < 8; i++) ok = hipEventCreate(&ctx->ev_dom[i >> 2][(i >> 1) & 1][i & 1]) == hipSuccess;
     ok = ok && hipMalloc(&ctx->d_status, sizeof(int32_t)) == hipSuccess;
     ok = ok && hipMalloc(&ctx->d_work, sizeof(unsigned)) == hipSuccess;
     ok = ok && hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * CNT_N) == hipSuccess;
@@ -319,6 +323,18 @@ extern "C" mtr_status mtr_create(int device, int manhattan, float min_match_rati
         }
         if (ok) { ctx->d_mt = g_mt[device].d; g_mt[device].refs++; }
     } else ok = false;
+    if (ok) {
+        // test knob (tests/test_gpu_parity.py: the WrapDPsize failure on the GPU): the limit the kernels test, per device; untouched unless asked for
+        static long long wrap_set[64];                           // what this process last wrote on the device (0 = the built-in 2e8)
+        const char *e = getenv("MTR_TEST_WRAP_DP_SIZE");
+        const long long want = e && atoll(e) > 0 ? atoll(e) : 0;
+        std::lock_guard<std::mutex> lk(g_mt_mu);
+        if (want != wrap_set[device]) {
+            const long long v = want ? want : (long long)MTRC_WRAP_DP_SIZE;
+            ok = hipMemcpyToSymbol(HIP_SYMBOL(mtr_dev_wrap_dp_size), &v, sizeof v) == hipSuccess;
+            if (ok) wrap_set[device] = want;
+        }
+    }
     if (!ok) { mtr_destroy(ctx); return MTR_ERR_NO_DEVICE; }
     *out = ctx;
     DBG("mtr_create: stream, events, small buffers, MT stream ready");
@@ -339,7 +355,8 @@ extern "C" void mtr_destroy(mtr_ctx *ctx)
     dfree(ctx->d_status); dfree(ctx->d_work); dfree(ctx->d_counters); dfree(ctx->d_scratch);
     dfree(ctx->d_trace); dfree(ctx->d_trace_n); dfree(ctx->d_fail_read);
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
-    for (int i = 0; i < MTR_N_KERNEL_TIMES; i++) { if (ctx->ev_ph[i]) (void)hipEventDestroy(ctx->ev_ph[i]); if (ctx->ev_ph2[i]) (void)hipEventDestroy(ctx->ev_ph2[i]); }
+    for (int i = 0; i < MTR_N_PHASE_TIMES; i++) { if (ctx->ev_ph[i]) (void)hipEventDestroy(ctx->ev_ph[i]); if (ctx->ev_ph2[i]) (void)hipEventDestroy(ctx->ev_ph2[i]); }
+    for (int i = 0; i < 8; i++) if (ctx->ev_dom[i >> 2][(i >> 1) & 1][i & 1]) (void)hipEventDestroy(ctx->ev_dom[i >> 2][(i >> 1) & 1][i & 1]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -681,7 +698,11 @@ static int staged_two_pass(int64_t bases, int n_reads)
     // deep batches of long reads take mode 1; every other big batch mode 2 - the chain then searches what the reference searches.
     const char *e = getenv("MTR_TWO_PASS");
     if (e) return atoi(e);
-    if (bases >= ((int64_t)16 << 20) && bases / std::max(n_reads, 1) >= 8000) return 1;
+    // Round 5: long reads take mode 1 from 2 M bases on (was 16 M).  What one pass searches beyond the reference grows with the read: x 5.9 the ranges and x 2.85
+    // the DP calls on 42 kb reads (config 3's 100 reads = 4.2 M bases, the batch the bench line and the command line run); a lone launch pays the
+    // second pass's tails (120.7 -> 127.4 ms), launches pipelined over two contexts - what both of them do - get the saved work.
+    static const long long long_min = getenv("MTR_TWO_PASS_LONG_MIN_BASES") ? atoll(getenv("MTR_TWO_PASS_LONG_MIN_BASES")) : ((long long)2 << 20);
+    if (bases >= long_min && bases / std::max(n_reads, 1) >= 8000) return 1;
     return bases >= 8000000 ? 2 : 0;
 }
 static unsigned st_sum(const unsigned long long *cls) { unsigned t = 0; for (int c = 0; c < ST_NCLS; c++) t += (unsigned)cls[c * 32]; return t; }
@@ -771,6 +792,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     s.item_pass = ctx->d_st_ipass; s.pass_list[0] = ctx->d_st_plist0; s.pass_list[1] = ctx->d_st_plist1; s.re2 = ctx->d_st_re2;
     s.n_pass[0] = (unsigned *)(sc + 6 * 32); s.n_pass[1] = (unsigned *)(sc + 7 * 32);
     ctx->last_two_pass = s.two_pass != 0;
+    ctx->last_quads = s.quad_min > 0;
     if (const char *e = getenv("MTR_TEST_STAGED_FLAGS")) s.test_flags = atoi(e);
     K1Layout y1 = k1_layout(ctx->Lmax); K2Layout y2 = k2_layout(ctx->Lmax);
     // few reads: the range finder as one wavefront per (read, pass) over per-READ scratch (launch_k1_parts), as in the
@@ -841,8 +863,10 @@ static mtr_status launch_staged(mtr_ctx *ctx)
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(mtr_k_qscatter, dim3((unsigned)capped(512, 16384)), dim3(256), 0, ctx->stream, s, ctx->d_status);
             HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(ctx->ev_dom[1][pass][0], ctx->stream));
             hipLaunchKernelGGL(mtr_k_dp2_quads, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
             HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(ctx->ev_dom[1][pass][1], ctx->stream));
         }
         if (s.quad_min <= 0) {                                  // (a big batch: mtr_k_dp2_quads has run them)
             hipLaunchKernelGGL(mtr_k_dp2_waves, dim3((unsigned)capped(waves_dp, 16)), dim3(64), 0, ctx->stream, a, s);
@@ -873,7 +897,9 @@ static mtr_status launch_staged(mtr_ctx *ctx)
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(mtr_k_rscatter, dim3((unsigned)capped(512, 16384)), dim3(256), 0, ctx->stream, s, ctx->d_status);
             HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(ctx->ev_dom[0][pass][0], ctx->stream));
             hipLaunchKernelGGL(mtr_k_revise_quads, dim3((unsigned)capped(waves, 256)), dim3(64), 0, ctx->stream, a, s);
+            HIPCHK(hipEventRecord(ctx->ev_dom[0][pass][1], ctx->stream));
         } else hipLaunchKernelGGL(mtr_k_revise, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(evp[6], ctx->stream));       // revisions
@@ -973,14 +999,14 @@ extern "C" mtr_status mtr_wait(mtr_ctx *ctx)
     float ms = 0;
     ctx->kt[0].ms = 0; ctx->kt[0].launches = 0;                // K1 runs inside the per-read kernel
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->kt[1].ms = ms; ctx->kt[1].launches = 1;
-    for (int p = 2; p < MTR_N_KERNEL_TIMES; p++) { ctx->kt[p].ms = 0; ctx->kt[p].launches = 0; }
+    for (int p = 2; p < MTR_N_PHASE_TIMES; p++) { ctx->kt[p].ms = 0; ctx->kt[p].launches = 0; }
     if (ctx->last_staged) {
         hipEvent_t prev = ctx->ev[2];
-        for (int p = 2; p < MTR_N_KERNEL_TIMES; p++) {
+        for (int p = 2; p < MTR_N_PHASE_TIMES; p++) {
             // (two passes: the first pass ends with its revisions, then mtr_k_finish, the mark pass and the second pass's phases 3..6, whose
             //  durations are added to the first's; the last phase = finish + mark + finish + replay)
-            hipEvent_t cur = p == MTR_N_KERNEL_TIMES - 1 ? ctx->ev[3] : ctx->ev_ph[p];
-            if (ctx->last_two_pass && p == MTR_N_KERNEL_TIMES - 1) {
+            hipEvent_t cur = p == MTR_N_PHASE_TIMES - 1 ? ctx->ev[3] : ctx->ev_ph[p];
+            if (ctx->last_two_pass && p == MTR_N_PHASE_TIMES - 1) {
                 float m1 = 0, m2 = 0;
                 HIPCHK(hipEventElapsedTime(&m1, ctx->ev_ph[6], ctx->ev_ph2[2])); HIPCHK(hipEventElapsedTime(&m2, ctx->ev_ph2[6], ctx->ev[3]));
                 ctx->kt[p].ms = m1 + m2; ctx->kt[p].launches = 2;
@@ -992,6 +1018,15 @@ extern "C" mtr_status mtr_wait(mtr_ctx *ctx)
                 HIPCHK(hipEventElapsedTime(&m2, ctx->ev_ph2[p - 1], ctx->ev_ph2[p])); ctx->kt[p].ms += m2; ctx->kt[p].launches = 2;
             }
             prev = cur;
+        }
+    }
+    for (int d = 0; d < 2; d++) {                            // ids 8, 9: mtr_k_revise_quads and mtr_k_dp2_quads by themselves (both passes)
+        ctx->kt[MTR_N_PHASE_TIMES + d].ms = 0; ctx->kt[MTR_N_PHASE_TIMES + d].launches = 0;
+        if (!ctx->last_staged || !ctx->last_quads) continue;
+        for (int pass = 0; pass < (ctx->last_two_pass ? 2 : 1); pass++) {
+            float m = 0;
+            HIPCHK(hipEventElapsedTime(&m, ctx->ev_dom[d][pass][0], ctx->ev_dom[d][pass][1]));
+            ctx->kt[MTR_N_PHASE_TIMES + d].ms += m; ctx->kt[MTR_N_PHASE_TIMES + d].launches++;
         }
     }
     HIPCHK(copy_sync(ctx, ctx->counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost));

@@ -55,6 +55,8 @@ int main(int argc, char **argv)
     mtrh_stamp("everything printed");
     double t_wait = 0, t_submit = 0, t_fetch = 0, t_kernel = 0; long long queries = 0;
     mtrh_run_timing(run, &t_wait, &t_submit, &t_fetch, &t_kernel, &queries);
+    double t_create = 0, ph[MTR_N_KERNEL_TIMES];
+    mtrh_run_phase_times(run, &t_create, ph, MTR_N_KERNEL_TIMES);
     char engine_path[4096];
     snprintf(engine_path, sizeof engine_path, "%s", mtrh_run_engine_path(run));
     mtrh_run_stop(run);
@@ -62,15 +64,25 @@ int main(int argc, char **argv)
     if (getenv("MTR_HOST_TIMING"))                /* development aid: phase times on stderr */
         fprintf(stderr, "[host] waiting for the parser threads %.3f s, upload+launch %.3f s, waiting for the device + fetch %.3f s (kernels %.3f s), chain+print %.3f s, all %.3f s\n",
                 t_wait, t_submit, t_fetch, t_kernel, t_chain, now() - t_all);
-    if (print_time) {                             /* the reference's -c block (main.c:108-121) */
+    if (print_time) {                             /* the reference's -c block (main.c:108-121), line for line.  Its timers sit around steps of ONE read at a
+                                                   * time on the host; here the steps are kernels over a batch, so the lines carry the device time of the
+                                                   * kernels that do that step (HIP events, mtr_get_kernel_times), summed over the batches:
+                                                   *   allocating memory      <- creating the device contexts (malloc_global_variables, handle_one_file.c:71-136)
+                                                   *   ranges                 <- the range kernels (fill_directional_index_with_end, handle_one_read.c:206-212)
+                                                   *   Computing periods      <- every other kernel of the launches + chaining (handle_one_read.c:217-258)
+                                                   *   Initialize the input   <- packing to 2 bit/base + upload + launch on the host (init_inputString, consensus.c:39-59)
+                                                   *   count table generation <- the unit-search kernels: k-mer tables, seeds, walks (consensus.c:73-127)
+                                                   *   wrap around            <- the alignment and revision kernels (wrap_around_DP_sub, wrap_around_DP.c:224-353)
+                                                   * a batch the per-read kernel took has no phases: its whole launch counts as "Computing periods" */
+        const double t_launches = ph[0] + ph[1], t_ranges = ph[2];
         fprintf(stderr, "Computation time\n");
         fprintf(stderr, "%f\tall\n", now() - t_all);
-        fprintf(stderr, "%f\tallocating memory\n", 0.0);
-        fprintf(stderr, "%f\tranges\n", 0.0);
-        fprintf(stderr, "%f\tComputing periods\n", t_kernel + t_chain);
-        fprintf(stderr, "\t%f\tInitialize the input\n", 0.0);
-        fprintf(stderr, "\t%f\tcount table generation\n", 0.0);
-        fprintf(stderr, "\t%f\twrap around\n", 0.0);
+        fprintf(stderr, "%f\tallocating memory\n", t_create);
+        fprintf(stderr, "%f\tranges\n", t_ranges);
+        fprintf(stderr, "%f\tComputing periods\n", (t_launches > t_ranges ? t_launches - t_ranges : 0.0) + t_chain);
+        fprintf(stderr, "\t%f\tInitialize the input\n", t_submit);
+        fprintf(stderr, "\t%f\tcount table generation\n", ph[3]);
+        fprintf(stderr, "\t%f\twrap around\n", ph[4] + ph[6]);
         fprintf(stderr, "\t%f\tchaining\n", t_chain);
         fprintf(stderr, "\t%i\tCount of queries\n", (int)queries);
         fprintf(stderr, "%s\tengine library%s\n", engine_path, getenv("MTR_LIB") ? " (from $MTR_LIB)" : "");   /* this build: what computed the records */

@@ -117,6 +117,7 @@ typedef struct mtrh_result {
     uint8_t *ops; int64_t *ops_off; int32_t *ends; uint8_t *after;   /* mtr_alignments' results per chained record; 2 bytes per read */
     int      fatal;  char *fatal_msg;      /* a device-side error: printed on stderr after n_report reads, exit status 1 */
     double   t_kernel_ms; int64_t queries;
+    double   t_phase_ms[MTR_N_KERNEL_TIMES];  /* device time by phase (mtr_get_kernel_times ids); not serialised */
 } mtrh_result;
 void   mtrh_result_free(mtrh_result *r);
 /* one self-contained byte string (malloc'ed) and back: what the multi-GPU launcher gathers to rank 0 */
@@ -145,6 +146,8 @@ int   mtrh_run_round_of(const mtrh_run *r, int chunk);
 mtrh_result *mtrh_run_next(mtrh_run *r);
 void  mtrh_run_timing(const mtrh_run *r, double *t_parse_wait, double *t_submit, double *t_fetch, double *t_kernel, long long *queries);
 const char *mtrh_run_engine_path(const mtrh_run *r);           /* the engine library the run bound (resolved path) */
+/* seconds spent creating the device contexts, and device time by phase of the chain (ids of mtr_get_kernel_times) summed over the batches: what mTR -c prints */
+void  mtrh_run_phase_times(const mtrh_run *r, double *t_create, double *t_phase, int n_phase);
 void  mtrh_stamp(const char *what);           /* development aid: with MTR_HOST_TIMING set, a line on stderr with the time since the first stamp */
 void  mtrh_run_stop(mtrh_run *r);
 /* all results this rank produces for `round`, serialised one after the other (malloc'ed; free() it) */

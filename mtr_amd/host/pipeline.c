@@ -22,6 +22,8 @@
 #define RESULT_QUEUE 4
 
 typedef struct { int file; size_t begin, end; int owner, round; } chunk_t;
+/* what the device thread holds while it runs (see device_main) */
+typedef struct { mtr_ctx *ctxs[2]; mtr_file_state *fs; mtrh_result *prev; mtr_ctx *prev_ctx; int *file_ended; char *dead_msg; } device_state;
 
 struct mtrh_run {
     mtrh_opts o; mtrh_engine eng;
@@ -34,9 +36,11 @@ struct mtrh_run {
     int n_parsers; pthread_t parsers[16], device;
     mtrh_result *queue[RESULT_QUEUE]; int q_head, q_n, device_done, stopping;
     double t_parse_wait, t_submit, t_fetch, t_kernel; long long queries;
+    double t_create, t_phase[MTR_N_KERNEL_TIMES];   /* seconds: creating the device contexts; device time by phase of the chain (mtr_get_kernel_times ids) */
     int overlap;                                   /* more than one device batch: launches of the two contexts overlap */
     int parse_failed;                              /* a parser thread could not allocate: the device thread reports it */
     int *chunk_done;                               /* per chunk: its last result has been handed on */
+    device_state dev;                              /* the device thread's state (well defined after a longjmp out of device_body) */
 };
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
@@ -247,13 +251,18 @@ static void finish_batch(mtrh_run *r, mtr_ctx *ctx, mtrh_result *x)
         }
     }
     x->n_report = n_report;
-    mtr_kernel_time kt[2] = { { 0, 0 }, { 0, 0 } };
-    if (r->eng.kernel_times(ctx, kt, 2) == MTR_OK) x->t_kernel_ms = (double)kt[0].ms + (double)kt[1].ms;
+    mtr_kernel_time kt[MTR_N_KERNEL_TIMES];
+    memset(kt, 0, sizeof kt);
+    if (r->eng.kernel_times(ctx, kt, MTR_N_KERNEL_TIMES) == MTR_OK) {
+        x->t_kernel_ms = (double)kt[0].ms + (double)kt[1].ms;
+        for (int i = 0; i < MTR_N_KERNEL_TIMES; i++) x->t_phase_ms[i] = (double)kt[i].ms;
+    }
     int64_t cnt[MTR_N_COUNTERS];
     if (r->eng.counters(ctx, cnt, MTR_N_COUNTERS) == MTR_OK) x->queries = cnt[8];
     if (r->o.print_alignment && n_report > 0) add_alignments(r, ctx, x);
     pthread_mutex_lock(&r->mu);
     r->t_fetch += now_s() - t0; r->t_kernel += x->t_kernel_ms * 1e-3; r->queries += x->queries;
+    for (int i = 0; i < MTR_N_KERNEL_TIMES; i++) r->t_phase[i] += x->t_phase_ms[i] * 1e-3;
     pthread_mutex_unlock(&r->mu);
     push_result(r, x);
 }
@@ -279,25 +288,29 @@ static void report_failure(mtrh_run *r, const char *msg)
 
 /* what the device thread holds while it runs: kept outside device_body so that a failed allocation (a longjmp out of it) still
  * finds the batch in flight and the contexts - they are waited for and destroyed, not left to the process's end */
-typedef struct { mtr_ctx *ctxs[2]; mtr_file_state *fs; mtrh_result *prev; mtr_ctx *prev_ctx; int *file_ended; char *dead_msg; } device_state;
 static void device_body(mtrh_run *r, device_state *d);
 static void *device_main(void *arg)
 {
     mtrh_run *r = (mtrh_run *)arg;
     jmp_buf oom;
-    device_state d; memset(&d, 0, sizeof d);
+    /* the state lives in the run (heap memory), not in this frame: an automatic variable changed between setjmp and longjmp is
+     * indeterminate afterwards (C11 7.13.2.1), and the clean-up below frees pointers and destroys contexts out of it */
+    device_state *d = &r->dev;
+    memset(d, 0, sizeof *d);
     mtrh_thread_kind = MTRH_THREAD_DEVICE;
     if (setjmp(oom)) {                                   /* an allocation of this thread failed (alloc.c) */
         mtrh_oom_target = NULL;
-        if (d.prev && d.prev_ctx) (void)r->eng.wait(d.prev_ctx);
-        mtrh_result_free(d.prev);
-        if (d.fs) r->eng.fs_destroy(d.fs);
-        for (int t = 0; t < 2; t++) if (d.ctxs[t]) { (void)r->eng.wait(d.ctxs[t]); r->eng.destroy(d.ctxs[t]); }
-        free(d.file_ended); free(d.dead_msg);
+        d = &r->dev;
+        if (d->prev && d->prev_ctx) (void)r->eng.wait(d->prev_ctx);
+        mtrh_result_free(d->prev);
+        if (d->fs) r->eng.fs_destroy(d->fs);
+        for (int t = 0; t < 2; t++) if (d->ctxs[t]) { (void)r->eng.wait(d->ctxs[t]); r->eng.destroy(d->ctxs[t]); }
+        free(d->file_ended); free(d->dead_msg);
+        memset(d, 0, sizeof *d);
         report_failure(r, "fatal error: cannot allocate memory");
     } else {
         mtrh_oom_target = &oom;
-        device_body(r, &d);
+        device_body(r, d);
         mtrh_oom_target = NULL;
     }
     pthread_mutex_lock(&r->mu);
@@ -370,7 +383,9 @@ static void device_body(mtrh_run *r, device_state *d)
             mtr_ctx **pc = &ctxs[k & 1];
             mtr_status st = MTR_OK;
             if (!*pc) {
+                const double tc = now_s();
                 st = r->eng.create(r->o.device, r->o.manhattan, r->o.min_match_ratio, pc);
+                pthread_mutex_lock(&r->mu); r->t_create += now_s() - tc; pthread_mutex_unlock(&r->mu);
                 mtrh_stamp(k == 0 ? "first device context created" : "second device context created");
                 if (st != MTR_OK) {
                     char m[256];
@@ -456,6 +471,11 @@ int mtrh_run_owner(const mtrh_run *r, int chunk) { return chunk >= 0 && chunk < 
 int mtrh_run_round_of(const mtrh_run *r, int chunk) { return chunk >= 0 && chunk < r->n_chunks ? r->chunks[chunk].round : -1; }
 
 const char *mtrh_run_engine_path(const mtrh_run *r) { return r->eng.path; }
+void mtrh_run_phase_times(const mtrh_run *r, double *t_create, double *t_phase, int n_phase)
+{
+    if (t_create) *t_create = r->t_create;
+    for (int i = 0; t_phase && i < n_phase; i++) t_phase[i] = i < MTR_N_KERNEL_TIMES ? r->t_phase[i] : 0.0;
+}
 void mtrh_run_timing(const mtrh_run *r, double *t_parse_wait, double *t_submit, double *t_fetch, double *t_kernel, long long *queries)
 {
     if (t_parse_wait) *t_parse_wait = r->t_parse_wait;

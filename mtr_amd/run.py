@@ -150,8 +150,13 @@ def join_process_group(dist, backend, rank, world):
     path = os.environ.get("MTR_RDZV_FILE")
     own_dir = None
     if not path and "MASTER_PORT" not in os.environ:
+        if world > 1:
+            # ranks somebody else started (mpirun, srun, a hand-rolled loop) with RANK / WORLD_SIZE but no meeting point: a private store per
+            # rank would leave every rank waiting for the others until the store's timeout, without a word
+            raise SystemExit("mtr_amd.run: RANK/WORLD_SIZE are set (world size %d) but neither MTR_RDZV_FILE nor MASTER_ADDR/MASTER_PORT say where the "
+                             "ranks meet; start the ranks with --gpus N, under torchrun, or export one of the two" % world)
         import tempfile
-        own_dir = tempfile.mkdtemp(prefix=f"mtr_run_{os.getpid()}_")
+        own_dir = tempfile.mkdtemp(prefix=f"mtr_run_{os.getpid()}_")      # the lone --force-dist process
         path = os.path.join(own_dir, "store")
     if path:
         dist.init_process_group(backend, init_method="file://" + path, rank=rank, world_size=world)

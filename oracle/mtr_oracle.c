@@ -26,7 +26,9 @@
 #define MAX_KMER 15
 #define MAX_TIEBREAKS 1024
 #define MIN_JACCARD 0.98
-#define WRAP_DP_SIZE 200000000
+/* mTR.h:51 WrapDPsize.  A variable so that the tests can make the failure reachable (MTR_TEST_WRAP_DP_SIZE, read by mtro_create - the same
+ * variable the HIP library reads): no input of at most 833 333 bases is known to reach 2e8 cells */
+static long long WRAP_DP_SIZE = 200000000;
 #define COUNT_MAX_KMER 6
 #define MAX_SEEDS 100
 #define ALIGN_WIDTH 50
@@ -117,6 +119,7 @@ static void *xrealloc(void *p, size_t n)
 
 mtro_ctx *mtro_create(int manhattan, float min_match_ratio)
 {
+    { const char *e = getenv("MTR_TEST_WRAP_DP_SIZE"); WRAP_DP_SIZE = e && atoll(e) > 0 ? atoll(e) : 200000000; }
     mtro_ctx *c = (mtro_ctx *)calloc(1, sizeof(*c));
     if (!c) return NULL;
     POW4[0] = 1; for (int i = 1; i <= MAX_KMER; i++) POW4[i] = POW4[i - 1] * 4;

@@ -25,6 +25,6 @@ for label, rs in (("single read", reads[:1]), (f"{n} reads", reads)):
     print(f"   traceback refills: {c['tb_refills']} taking {c['cyc_tb_refill']/1e6:.1f} M cycles = {c['cyc_tb_refill']/max(c['tb_refills'],1):.0f} per refill; memo hits {c['memo_hits']}, tables skipped {c['tables_skipped']}")
     print(f"   walk steps {c['walk_steps']}, of which {c['walk_slow_steps']} through the general look-ahead taking {c['cyc_walk_slow']/1e6:.1f} M cycles")
     print(f"   walk calls {c['walk_calls']} ({c['walk_closed']} closed a cycle), cycles inside walk_fast {c['cyc_walk_fast']/1e6:.1f} M")
-    print(f"   revisions {c['spare44']}, unit unchanged by the votes in {c['spare43']}, accepted: round 0 {c['spare45']}, round 1 {c['spare46']}")
-    print(f"   two-parameter forward passes of units <= 16 bases: {c['spare47']/1e6:.1f} M cycles")
+    print(f"   revisions {c['prof44']}, unit unchanged by the votes in {c['prof43']}, accepted: round 0 {c['prof45']}, round 1 {c['prof46']}")
+    print(f"   two-parameter forward passes of units <= 16 bases: {c['prof47']/1e6:.1f} M cycles")
     print("   counts:", {k: c[k] for k in ("dp_calls", "dp_rows", "dp_cells", "traceback_steps", "kmer_tables", "kmer_lookups", "ranges_executed")})

@@ -11,6 +11,7 @@ Three kinds of evidence:
      run-to-run determinism, and a random sample against the oracle.
 """
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -120,14 +121,23 @@ def test_records_match_oracle(eng, eng_p, config, n, seed, manhattan):
     assert not bad, f"{len(bad)} of {n} reads differ\n" + "\n".join(bad[:3])
 
 
-def test_min_match_ratio_option(oracle):
+@pytest.mark.parametrize("ratio", [0.0, 0.8, 1.0])
+def test_min_match_ratio_option(ratio):
+    """-m (main.c:66-73, min_match_ratio of handle_one_read.c:139 / consensus.c:563): 0 lets every candidate through the ratio gate, 1 only
+    perfect alignments - exact repeats are in the set so that -m 1 reports something"""
     from tests.oracle_binding import Oracle
-    orc = Oracle(min_match_ratio=0.8)
-    e = mtr_amd.Engine(min_match_ratio=0.8)
+    orc = Oracle(min_match_ratio=ratio)
+    e = mtr_amd.Engine(min_match_ratio=ratio)
+    rng = np.random.RandomState(31)
     reads = [c for _, c in synth.make_reads("c2", 40, 31)]
+    reads += [synth.make_read(rng, u, c, 60, 60, profile=(0, 0, 0))[0] for u, c in ((3, 40), (7, 30), (24, 12), (100, 8))]
     got = e.process(reads)
+    n_rec = 0
     for i, codes in enumerate(reads):
-        assert [tuple(r) for r in got[i]] == orc.process(codes)
+        want = orc.process(codes)
+        assert [tuple(r) for r in got[i]] == want, _diff_msg(i, want, [tuple(r) for r in got[i]])
+        n_rec += len(want)
+    assert n_rec > 0
     e.close()
     orc.close()
 
@@ -161,6 +171,15 @@ def test_full_size_batch_independence_and_sample(eng, oracle):
     full = eng.fetch()
     cnt = eng.counters()
     assert cnt["records"] == sum(len(r) for r in full)
+    # the DEFAULT selection for a batch of 20 M bases (no MTR_* override in this test): the chain in two passes with every wide range first
+    # (k3_staged.hip.inc: mtr_k_pass_mark).  The mark pass's list of ranges is not provably a superset of what the reference's loop reaches; a miss
+    # is a silent per-read re-run, so it must show here: no read may have been sent back, and the chain searches what the loop reaches (+ a few %)
+    assert not any(k in os.environ for k in ("MTR_TWO_PASS", "MTR_STAGED", "MTR_QUAD_MIN"))
+    assert eng.last_mode() == "staged chain"
+    assert cnt["reads_sent_back"] == 0, cnt["reads_sent_back"]
+    assert cnt["ranges_searched"] < 1.05 * cnt["ranges_executed"], (cnt["ranges_searched"], cnt["ranges_executed"])
+    kt = eng.kernel_times_ms()
+    assert all(kt.get("chain_" + p, 0) > 0 for p in ("ranges", "unit_search", "alignments", "revisions")), kt
     # determinism: a second run of the same resident batch gives the same records
     eng.run()
     again = eng.fetch()
@@ -443,6 +462,193 @@ def test_config4_mixed_lengths_every_read(eng):
         want = [w for ch in pool.map(_oracle_chunk, chunks) for w in ch]
     bad = [i for i in range(len(reads)) if [tuple(r) for r in got[i]] != want[i]]
     assert not bad, f"{len(bad)} of {len(reads)} reads differ, first: " + _diff_msg(bad[0], want[bad[0]], [tuple(r) for r in got[bad[0]]])
+
+
+# ---- promoted from the builder-side sweeps (tests/dev/gpu_fuzz.py) into the driver-run suite ------------------------
+def _pool_oracle(args):
+    manhattan, reads = args
+    from tests.oracle_binding import Oracle
+    o = Oracle(manhattan=manhattan)
+    out = [o.process(r) for r in reads]
+    o.close()
+    return out
+
+
+def _oracle_all(reads, manhattan=True, workers=8):
+    from concurrent.futures import ProcessPoolExecutor
+    order = np.argsort([-len(r) for r in reads])
+    parts = [[int(i) for i in order[j::workers * 4]] for j in range(workers * 4)]
+    parts = [p for p in parts if p]
+    want = [None] * len(reads)
+    with ProcessPoolExecutor(max_workers=workers) as pool:
+        for idx, res in zip(parts, pool.map(_pool_oracle, [(manhattan, [reads[i] for i in p]) for p in parts])):
+            for i, w in zip(idx, res):
+                want[i] = w
+    return want
+
+
+def _period_limit_reads(seed, n):
+    """units of 440..530 bases around MAX_PERIOD 500 (mTR.h:35): walks that close only above the limit (consensus.c:542-581 `period < 500`),
+    revised units that reach string[500] (consensus.c:1012), candidates dropped by `period < MAX_PERIOD`"""
+    rng = np.random.RandomState(seed)
+    reads = []
+    for t in range(n):
+        u = int(rng.randint(440, 531)) if t >= 6 else (440, 498, 499, 500, 501, 530)[t]
+        c = int(rng.randint(6, 12))
+        prof = [(0, 0, 0), (0.5, 1, 1), synth.NANOPORE][t % 3]
+        reads.append(synth.make_read(rng, u, c, int(rng.randint(0, 300)), int(rng.randint(0, 300)), profile=prof)[0])
+    return reads
+
+
+_PERIOD_CACHE = {}
+
+
+@pytest.mark.parametrize("manhattan", [True, False])
+@pytest.mark.parametrize("mode", ["per_read", "staged", "staged_quads", "staged_two_pass_quads"])
+def test_units_at_the_period_limit(monkeypatch, mode, manhattan):
+    for k, v in MODES[mode].items():
+        monkeypatch.setenv(k, v)
+    reads = _period_limit_reads(440 + int(manhattan), 18)
+    if manhattan not in _PERIOD_CACHE:
+        _PERIOD_CACHE[manhattan] = _oracle_all(reads, manhattan)
+    want = _PERIOD_CACHE[manhattan]
+    e = mtr_amd.Engine(manhattan=manhattan)
+    got = e.process(reads)
+    e.close()
+    bad = [i for i in range(len(reads)) if [tuple(r) for r in got[i]] != want[i]]
+    assert not bad, f"{len(bad)} of {len(reads)} reads differ\n" + _diff_msg(bad[0], want[bad[0]], [tuple(r) for r in got[bad[0]]])
+    assert sum(len(w) for w in want) > 0
+    assert any(r[3] >= 400 for w in want for r in w), "no reported unit near the limit: the set does not test what it is for"
+
+
+def _fuzz_slice(seed):
+    """a slice of tests/dev/gpu_fuzz.py: every length 1..40, homopolymers, nested repeats (a unit made of a sub-repeat + a spacer), adjacent repeats
+    without a spacer, skewed composition, one short unit over a long read, repeats flush with an end and cut inside a copy"""
+    rng = np.random.RandomState(seed)
+    R = lambda n: rng.randint(0, 4, size=n).astype(np.uint8)
+    reads = []
+    for L in range(1, 41):
+        reads.append(R(L)); reads.append(np.full(L, L % 4, np.uint8))
+    for b in range(4):
+        for L in (64, 999, 1000, 1001, 3000):
+            reads.append(np.full(L, b, np.uint8))
+    for _ in range(24):
+        sub = R(int(rng.randint(2, 6))); unit = np.concatenate([np.tile(sub, int(rng.randint(3, 8))), R(int(rng.randint(1, 12)))])
+        body = np.tile(unit, int(rng.randint(6, 30)))
+        body = np.where(rng.rand(len(body)) < 0.03, R(len(body)), body).astype(np.uint8)
+        reads.append(np.concatenate([R(int(rng.randint(0, 200))), body, R(int(rng.randint(0, 200)))]))
+    for _ in range(24):
+        parts = [synth.make_read(rng, int(rng.choice([2, 3, 4, 5, 7, 11, 24, 60, 130])), int(rng.randint(6, 40)), 0, 0, profile=(1, 2, 2))[0]
+                 for _k in range(int(rng.randint(2, 4)))]
+        reads.append(np.concatenate(parts))
+    for _ in range(16):
+        p = rng.dirichlet([0.3, 0.3, 0.3, 0.3]); L = int(rng.randint(50, 4000))
+        reads.append(rng.choice(4, size=L, p=p).astype(np.uint8))
+    for _ in range(4):
+        u = R(int(rng.randint(1, 9))); L = int(rng.randint(3000, 12000))
+        body = np.tile(u, L // len(u) + 1)[:L]
+        reads.append(np.where(rng.rand(L) < rng.choice([0, 0.01, 0.05]), R(L), body).astype(np.uint8))
+    for _ in range(24):
+        u = int(rng.choice([2, 3, 5, 8, 13, 21, 34, 55, 89, 144])); body, _ = synth.make_read(rng, u, int(rng.randint(6, 30)), 0, 0, profile=(1, 3, 2))
+        body = body[int(rng.randint(0, u)): len(body) - int(rng.randint(0, u))]
+        reads.append(np.concatenate([body, R(int(rng.randint(0, 500)))]) if rng.randint(0, 2) else np.concatenate([R(int(rng.randint(0, 500))), body]))
+    return reads
+
+
+@pytest.mark.parametrize("manhattan", [True, False])
+def test_fuzz_slice_nested_adjacent_and_flush_repeats(monkeypatch, manhattan):
+    reads = _fuzz_slice(7 + int(manhattan))
+    want = _oracle_all(reads, manhattan)
+    for mode in ("per_read", "staged", "staged_quads", "staged_two_pass_quads"):
+        for k in ("MTR_STAGED", "MTR_QUAD_MIN", "MTR_TWO_PASS", "MTR_TEST_STAGED_CAPS", "MTR_TEST_STAGED_FLAGS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in MODES[mode].items():
+            monkeypatch.setenv(k, v)
+        e = mtr_amd.Engine(manhattan=manhattan)
+        got = e.process(reads) if mode != "staged" else [r for b in range(0, len(reads), 100) for r in e.process(reads[b:b + 100])]     # (batches of 100: the range finder of few reads)
+        e.close()
+        bad = [i for i in range(len(reads)) if [tuple(r) for r in got[i]] != want[i]]
+        assert not bad, f"[{mode}] {len(bad)} of {len(reads)} reads differ, first (L = {len(reads[bad[0]])})\n" + _diff_msg(bad[0], want[bad[0]], [tuple(r) for r in got[bad[0]]])
+    assert sum(len(w) for w in want) > 100
+
+
+# ---- the WrapDPsize failure, raised by the KERNELS (wrap_around_DP.c:95-99 / :259-262 exit; handle_one_read.c:89-91 clears the record) ------
+WRAP_LIMIT = 40000          # cells; the built-in 2e8 is not known to be reachable by a read of at most 833 333 bases, so both sides are lowered
+
+
+def _oracle_fails(codes, tmp_path, env):
+    """does reference semantics exit inside this read?  The oracle exits like the reference, so it runs as a child process."""
+    from tests.oracle_binding import ORACLE_DIR
+    fa = tmp_path / "one.fa"
+    synth.write_fasta(str(fa), [("r", codes)])
+    p = subprocess.run([os.path.join(ORACLE_DIR, "mtr_oracle_cli"), str(fa)], capture_output=True, env=env)
+    if p.returncode != 0:
+        assert b"WrapDPsize" in p.stderr, p.stderr[-300:]
+    return p.returncode != 0
+
+
+@pytest.mark.parametrize("mode", ["per_read", "staged", "staged_quads", "staged_two_pass_quads"])
+def test_dp_too_large_is_raised_by_the_kernels(monkeypatch, tmp_path, mode):
+    """MTR_TEST_WRAP_DP_SIZE lowers WrapDPsize in the kernels (device_util.hip.inc: mtr_dev_wrap_dp_size) and in the oracle alike.  The batch: reads
+    whose DPs all stay below the limit, then reads with windows x units beyond it.  The library must return MTR_ERR_DP_TOO_LARGE, name the FIRST read
+    (input order) in which the reference would have exited, and still hand over the records of the reads before it - the reference has printed them."""
+    monkeypatch.setenv("MTR_TEST_WRAP_DP_SIZE", str(WRAP_LIMIT))
+    for k, v in MODES[mode].items():
+        monkeypatch.setenv(k, v)
+    env = dict(os.environ)
+    rng = np.random.RandomState(60)
+    small = [rng.randint(0, 4, size=n).astype(np.uint8) for n in (700, 1500)] + [np.tile(np.array([3, 3, 0, 2, 2, 2], np.uint8), 60)]
+    small += [synth.make_read(rng, 12, 14, 100, 100)[0], synth.make_read(rng, 30, 9, 50, 300)[0]]
+    big = [c for _, c in synth.make_reads("headline2k", 6, 61)]                     # unit 100 x 10 copies: windows of ~1 000 rows x 100 columns
+    reads = small + big[:3] + small[:2] + big[3:]
+    fails = [_oracle_fails(c, tmp_path, env) for c in reads]
+    assert not any(fails[:len(small)]) and any(fails), fails
+    first = fails.index(True)
+    from tests.oracle_binding import Oracle
+    orc = Oracle()                                              # (created under the lowered limit: handle_one_read.c:89-91's clear is part of the records)
+    want = [orc.process(c) for c in reads[:first]]
+    orc.close()
+    e = mtr_amd.Engine()
+    with pytest.raises(mtr_amd.MtrError, match="MTR_ERR_DP_TOO_LARGE"):
+        e.process(reads)
+    assert e.first_failed_read() == first, (e.first_failed_read(), first, fails)
+    data, counts = e.fetch_packed(first)
+    assert list(counts) == [len(w) for w in want]
+    recs = (mtr_amd.CRecord * max(int(counts.sum()), 1))()
+    import ctypes as C
+    buf = C.create_string_buffer(data, len(data)) if data else C.create_string_buffer(1)
+    assert e.lib.mtr_unpack_records(buf, len(data), int(counts.sum()), recs) == 0
+    got = e._unpack(recs, counts, first)
+    for i in range(first):
+        assert [tuple(r) for r in got[i]] == want[i], _diff_msg(i, want[i], [tuple(r) for r in got[i]])
+    assert sum(len(w) for w in want) > 0
+    # the same batch without its failing reads runs clean on the same context (the failure is latched per run, not per context)
+    ok_reads = [c for c, f in zip(reads, fails) if not f]
+    orc = Oracle()
+    got = e.process(ok_reads)
+    for i, c in enumerate(ok_reads):
+        assert [tuple(r) for r in got[i]] == orc.process(c)
+    orc.close()
+    e.close()
+
+
+def test_dp_too_large_on_the_command_line(monkeypatch, tmp_path):
+    """mTR (the C host) on the same input: the reads before the failing one are printed, then the reference's message, then a failing exit status -
+    byte for byte what the oracle's command line prints before IT exits (handle_one_file.c:281-287 prints read by read)."""
+    from tests.oracle_binding import ORACLE_DIR
+    monkeypatch.setenv("MTR_TEST_WRAP_DP_SIZE", str(WRAP_LIMIT))
+    rng = np.random.RandomState(62)
+    reads = [synth.make_read(rng, 12, 14, 100, 100)[0], synth.make_read(rng, 30, 9, 50, 300)[0], np.tile(np.array([3, 3, 0, 2, 2, 2], np.uint8), 60)]
+    reads += [c for _, c in synth.make_reads("headline2k", 3, 63)] + [synth.make_read(rng, 5, 30, 10, 10)[0]]
+    fa = tmp_path / "reads.fa"
+    synth.write_fasta(str(fa), [(f"read{i}", c) for i, c in enumerate(reads)])
+    o = subprocess.run([os.path.join(ORACLE_DIR, "mtr_oracle_cli"), str(fa)], capture_output=True)
+    assert o.returncode != 0 and b"WrapDPsize" in o.stderr and o.stdout.count(b"\n") >= 3
+    subprocess.run(["make", "-s", "-C", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mtr_amd", "host"), "mTR"], check=True)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mtr_amd", "host", "mTR")
+    p = subprocess.run([exe, str(fa)], capture_output=True)
+    assert p.returncode != 0 and b"WrapDPsize" in p.stderr, p.stderr[-300:]
+    assert p.stdout == o.stdout
 
 
 # ---- file-order mode: the reference's behaviour on a multi-read file ---------------------------------------------------

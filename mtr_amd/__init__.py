@@ -270,9 +270,9 @@ class Engine:
         recs = C.POINTER(CRecord)()
         cnts = C.POINTER(C.c_int32)()
         total = C.c_int64()
+        self.n_reads = len(reads)                       # (before the call: after MTR_ERR_DP_TOO_LARGE the reads before the failing one are still fetched)
         self._check(self.lib.mtr_process_batch(self.h, bases.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(reads),
                                                C.byref(recs), C.byref(cnts), C.byref(total)), "mtr_process_batch")
-        self.n_reads = len(reads)
         try:
             return self._unpack(recs, cnts, len(reads))
         finally:

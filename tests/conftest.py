@@ -4,6 +4,11 @@ import sys
 
 import pytest
 
+try:        # PyTorch ships its own HIP runtime (same soname as /opt/rocm's, which libmtr_hip.so links): whichever is loaded first serves both, and
+    import torch  # noqa: F401  torch finds no GPU through the other one - so torch first, whatever subset of the test files is run
+except Exception:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -39,7 +39,7 @@ extern "C" {
 /* Longest read the hot path takes: the reference's buffers hold L + 2r entries with r = L/10 random flank bases
  * (handle_one_read.c:194-204), so beyond L + 2r = MAX_INPUT_LENGTH it writes out of bounds; uploads refuse such reads. */
 #define MTR_MAX_READ_LENGTH 833333
-#define MTR_ABI_VERSION 4
+#define MTR_ABI_VERSION 5
 
 typedef enum {
     MTR_OK = 0,
@@ -160,6 +160,31 @@ mtr_status mtr_export_packed_device(mtr_ctx *ctx, void *d_dst, int64_t capacity_
 mtr_status mtr_unpack_records(const uint8_t *blob, int64_t bytes, int64_t n_records, mtr_record *out);
 /* returns the number of bytes written, or -1 if capacity is too small */
 int64_t    mtr_pack_records(const mtr_record *records, int64_t n_records, uint8_t *out, int64_t capacity);
+
+/* ---- several GPUs in ONE process: the one exchange of the path (ABI 5) --------------------------------------------------
+ * Reads shard over the GPUs of a node (isolated semantics make every read an independent unit); what is left
+ * of handle_one_file.c:281-287's loop across GPUs is ONE exchange: the record tables travel to the process that chains and
+ * prints (chaining.cpp).  A mtr_gather owns an RCCL communicator per GPU (ncclCommInitAll: one process, N devices) and
+ * moves the wire form device to device over xGMI to the first GPU, from there in one copy to pinned host memory:
+ *   mtr_gather_stage     a GPU's finished batch (after mtr_wait) is compacted to the wire form into a staging buffer on ITS OWN
+ *                        device; returns a ticket.  Thread-safe: every GPU's host thread calls it for its own batches.
+ *   mtr_gather_exchange  the staged tables named by tickets[0..n) - any number per GPU - go to the first GPU:
+ *                        ncclGroupStart; per ticket ncclSend on the owner's communicator + ncclRecv on the first GPU's;
+ *                        ncclGroupEnd; then ONE device-to-host copy.  out_ptrs[i] / out_bytes[i] = ticket i's table in pinned
+ *                        host memory owned by the gather, valid until the next exchange; the tickets are released.  One
+ *                        caller at a time.  Tables of the first GPU itself skip the collective (MTR_GATHER_SELF=1 sends
+ *                        them through ncclSend/ncclRecv to itself as well: the RCCL path on a one-GPU box).
+ * devices[] must be distinct (RCCL refuses a device twice); librccl.so is bound at run time by mtr_gather_create and only
+ * there, so a single-GPU process never loads it.  MTR_ERR_NO_DEVICE: RCCL missing / communicator not created (the text is
+ * in mtr_gather_last_error); a host that gets it fetches every GPU's tables with mtr_fetch_results_packed instead. */
+typedef struct mtr_gather mtr_gather;
+mtr_status mtr_device_count(int32_t *out_count);
+mtr_status mtr_gather_create(int32_t n_ranks, const int32_t *devices, mtr_gather **out);
+void       mtr_gather_destroy(mtr_gather *g);
+const char *mtr_gather_last_error(const mtr_gather *g);
+mtr_status mtr_gather_stage(mtr_gather *g, int32_t rank, mtr_ctx *ctx, int32_t *counts_host, int64_t *out_total_records,
+                            int64_t *out_bytes, int32_t *out_ticket);
+mtr_status mtr_gather_exchange(mtr_gather *g, int32_t n_tickets, const int32_t *tickets, const uint8_t **out_ptrs, int64_t *out_bytes);
 
 /* File-order mode = the reference's own behaviour on a multi-read file (leak A, and H2) instead of
  * isolated semantics.  The reference's inputString_w_rand and orgInputString live for the whole file

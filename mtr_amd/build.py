@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmtr_hip.so")
 SOURCES = ["mtr_abi.hip", "mtr_common.h", "device_util.hip.inc", "k1_ranges.hip.inc", "k2_units.hip.inc", "k3_staged.hip.inc",
-           "dp_wrap.hip.inc", "dp_quad.hip.inc", "min_missing_table.h", os.path.join("..", "..", "include", "mtr_hip.h")]
+           "dp_wrap.hip.inc", "dp_quad.hip.inc", "gather.hip.inc", "min_missing_table.h", os.path.join("..", "..", "include", "mtr_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=off", "-fno-fast-math",      # fp64 DI values and float ratios must round exactly like the reference's C
          "-fhip-fp32-correctly-rounded-divide-sqrt",

@@ -1563,3 +1563,6 @@ extern "C" mtr_status mtr_get_trace(mtr_ctx *ctx, int32_t **out_events, int64_t 
     *out_events = ev; *out_n = n;
     return MTR_OK;
 }
+
+// ---- several GPUs in one process: the RCCL gather of the wire-form tables (include/mtr_hip.h, ABI 5) --------------------------------
+#include "gather.hip.inc"

@@ -45,6 +45,8 @@ int mtrh_engine_load(mtrh_engine *e, const char *lib_path, char *err, size_t err
     BIND(first_failed, "mtr_get_first_failed_read"); BIND(alignments, "mtr_alignments"); BIND(bases_after, "mtr_get_bases_after_read");
     BIND(kernel_times, "mtr_get_kernel_times"); BIND(counters, "mtr_get_counters");
     BIND(fs_create, "mtr_file_state_create"); BIND(fs_destroy, "mtr_file_state_destroy"); BIND(fs_skip, "mtr_file_state_skip");
+    BIND(device_count, "mtr_device_count"); BIND(gather_create, "mtr_gather_create"); BIND(gather_destroy, "mtr_gather_destroy");
+    BIND(gather_last_error, "mtr_gather_last_error"); BIND(gather_stage, "mtr_gather_stage"); BIND(gather_exchange, "mtr_gather_exchange");
     __typeof__(mtr_abi_version) *ver = NULL;
     *(void **)(&ver) = dlsym(e->dl, "mtr_abi_version");
     if (!ver || ver() != MTR_ABI_VERSION) {

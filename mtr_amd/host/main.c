@@ -16,18 +16,19 @@ static void usage(void)
     fprintf(stderr, "-m ratio: Give a minimum match ratio ranging from 0 to 1.\n");
     fprintf(stderr, "-p: Use Pearson's correlation coefficient distance in place of Manhattan distance.\n");
     fprintf(stderr, "-d n: (this build) use GPU n.  -B: (this build) results of a read depend on the longer reads before it in the file, as in reference mTR.\n");
+    fprintf(stderr, "-g N: (this build) shard the reads over N GPUs of this node (one process; the record tables are gathered to the first GPU over RCCL); several files may follow.\n");
 }
 
 static double now(void) { struct timeval t; gettimeofday(&t, NULL); return t.tv_sec + t.tv_usec * 1.0E-6; }
 
 int main(int argc, char **argv)
 {
-    int print_time = 0;
+    int print_time = 0, n_gpus = 0;
     mtrh_opts o; memset(&o, 0, sizeof o);
     o.manhattan = 1; o.min_match_ratio = 0.6f;    /* MIN_MATCH_RATIO, mTR.h:32 */
     o.world = 1;
     int opt;
-    while ((opt = getopt(argc, argv, "acm:pd:B")) != -1) {
+    while ((opt = getopt(argc, argv, "acm:pd:Bg:")) != -1) {
         switch (opt) {
         case 'a': o.print_alignment = 1; break;
         case 'c': print_time = 1; break;
@@ -37,29 +38,62 @@ int main(int argc, char **argv)
             break;
         case 'p': o.manhattan = 0; fprintf(stderr, "Pearson's correlation coefficient distance in place of Manhattan distance.\n"); break;
         case 'd': o.device = atoi(optarg); break;      /* extension: GPU ordinal */
+        case 'g': n_gpus = atoi(optarg);               /* extension: the GPUs of one node (multi.c) */
+            if (n_gpus < 1 || n_gpus > 64) { fprintf(stderr, "-g takes a number of GPUs from 1 to 64.\n"); exit(EXIT_FAILURE); }
+            break;
         case 'B': o.file_order = 1; break;             /* extension: the reference's whole-file behaviour (mtr_hip.h, file-order mode) */
         default: usage(); exit(EXIT_FAILURE);
         }
     }
+    { const char *cb = getenv("MTR_CHUNK_BYTES"); if (cb && atoll(cb) > 0) o.chunk_bytes = (size_t)atoll(cb); }     /* FASTA bytes per chunk (default 24 MiB = one device batch of 2 kb reads) */
     if (optind >= argc) { fprintf(stderr, "The input file name is expected argument after options\n"); exit(EXIT_FAILURE); }
 
     const double t_all = now();
-    const char *paths[1] = { argv[optind] };
-    mtrh_run *run = mtrh_run_start(&o, paths, 1);
-    if (!run) exit(EXIT_FAILURE);
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-    mtrh_printer *pr = mtrh_printer_start(stdout, ncpu >= 8 ? 4 : (ncpu >= 4 ? 2 : 1));
-    for (mtrh_result *x; (x = mtrh_run_next(run)) != NULL; ) mtrh_printer_push(pr, x);
-    double t_chain = 0;
-    const int status = mtrh_printer_finish(pr, &t_chain);
+    mtrh_run *run = NULL; mtrh_multi *multi = NULL;
+    int status = 0; double t_chain = 0;
+    if (n_gpus >= 1) {
+        /* the GPUs of one node in this process: one run per GPU, the record tables gathered to the first GPU over RCCL (multi.c) */
+        /* stdout belongs to the report: RCCL prints its version banner on descriptor 1 at the first collective, so the report keeps a descriptor
+         * of its own and descriptor 1 points at stderr for the rest of the process */
+        fflush(stdout);
+        const int report_fd = dup(1);
+        if (report_fd < 0 || dup2(2, 1) < 0) { fprintf(stderr, "fatal error: cannot set the report's descriptor aside\n"); exit(EXIT_FAILURE); }
+        multi = mtrh_multi_start(&o, n_gpus, (const char *const *)(argv + optind), argc - optind);
+        if (!multi) exit(EXIT_FAILURE);
+        mtrh_printer *pr = mtrh_printer_start_fd(report_fd, ncpu >= 8 ? 4 : (ncpu >= 4 ? 2 : 1));
+        const int drained = mtrh_multi_drain(multi, pr);
+        status = mtrh_printer_finish(pr, &t_chain);
+        if (drained != 0) status = 1;
+    } else {
+        const char *paths[1] = { argv[optind] };
+        run = mtrh_run_start(&o, paths, 1);
+        if (!run) exit(EXIT_FAILURE);
+        mtrh_printer *pr = mtrh_printer_start(stdout, ncpu >= 8 ? 4 : (ncpu >= 4 ? 2 : 1));
+        for (mtrh_result *x; (x = mtrh_run_next(run)) != NULL; ) mtrh_printer_push(pr, x);
+        status = mtrh_printer_finish(pr, &t_chain);
+    }
     mtrh_stamp("everything printed");
     double t_wait = 0, t_submit = 0, t_fetch = 0, t_kernel = 0; long long queries = 0;
-    mtrh_run_timing(run, &t_wait, &t_submit, &t_fetch, &t_kernel, &queries);
     double t_create = 0, ph[MTR_N_KERNEL_TIMES];
-    mtrh_run_phase_times(run, &t_create, ph, MTR_N_KERNEL_TIMES);
-    char engine_path[4096];
-    snprintf(engine_path, sizeof engine_path, "%s", mtrh_run_engine_path(run));
-    mtrh_run_stop(run);
+    memset(ph, 0, sizeof ph);
+    char engine_path[4096], gather_line[512] = "";
+    for (int g = 0; g < (multi ? mtrh_multi_n(multi) : 1); g++) {        /* (several GPUs: the sums over the GPUs, which work side by side) */
+        const mtrh_run *rg = multi ? mtrh_multi_run(multi, g) : run;
+        double a = 0, b = 0, c = 0, d = 0, tc = 0, p8[MTR_N_KERNEL_TIMES]; long long q = 0;
+        mtrh_run_timing(rg, &a, &b, &c, &d, &q);
+        mtrh_run_phase_times(rg, &tc, p8, MTR_N_KERNEL_TIMES);
+        t_wait += a; t_submit += b; t_fetch += c; t_kernel += d; queries += q; t_create += tc;
+        for (int i = 0; i < MTR_N_KERNEL_TIMES; i++) ph[i] += p8[i];
+        if (g == 0) snprintf(engine_path, sizeof engine_path, "%s", mtrh_run_engine_path(rg));
+    }
+    if (multi) {
+        long long nx = 0, nb = 0;
+        const char *mode = mtrh_multi_gather_mode(multi, &nx, &nb);
+        snprintf(gather_line, sizeof gather_line, "%d GPUs\tgather %s, %lld exchange(s), %lld bytes of record tables%s%s%s", mtrh_multi_n(multi), mode, nx, nb,
+                 mtrh_multi_gather_note(multi)[0] ? " (" : "", mtrh_multi_gather_note(multi), mtrh_multi_gather_note(multi)[0] ? ")" : "");
+        mtrh_multi_stop(multi);
+    } else mtrh_run_stop(run);
     mtrh_stamp("run stopped");
     if (getenv("MTR_HOST_TIMING"))                /* development aid: phase times on stderr */
         fprintf(stderr, "[host] waiting for the parser threads %.3f s, upload+launch %.3f s, waiting for the device + fetch %.3f s (kernels %.3f s), chain+print %.3f s, all %.3f s\n",
@@ -86,6 +120,7 @@ int main(int argc, char **argv)
         fprintf(stderr, "\t%f\tchaining\n", t_chain);
         fprintf(stderr, "\t%i\tCount of queries\n", (int)queries);
         fprintf(stderr, "%s\tengine library%s\n", engine_path, getenv("MTR_LIB") ? " (from $MTR_LIB)" : "");   /* this build: what computed the records */
+        if (gather_line[0]) fprintf(stderr, "%s\n", gather_line);                 /* this build, -g N: how the tables reached the printer */
     }
     return status ? EXIT_FAILURE : EXIT_SUCCESS;
 }

@@ -60,6 +60,13 @@ typedef struct mtrh_engine {
     __typeof__(mtr_file_state_create) *fs_create;
     __typeof__(mtr_file_state_destroy) *fs_destroy;
     __typeof__(mtr_file_state_skip) *fs_skip;
+    /* several GPUs in one process (ABI 5) */
+    __typeof__(mtr_device_count) *device_count;
+    __typeof__(mtr_gather_create) *gather_create;
+    __typeof__(mtr_gather_destroy) *gather_destroy;
+    __typeof__(mtr_gather_last_error) *gather_last_error;
+    __typeof__(mtr_gather_stage) *gather_stage;
+    __typeof__(mtr_gather_exchange) *gather_exchange;
     char path[4096];                    /* the library that was bound, resolved (reported by mTR -c) */
 } mtrh_engine;
 /* dlopen a library that implements include/mtr_hip.h; lib_path NULL = $MTR_LIB, else libmtr_hip.so next to this code */
@@ -111,6 +118,7 @@ typedef struct mtrh_result {
     mtrh_batch *batch;                     /* ids, lens, (codes) */
     int32_t  n_report;                     /* reads to report: batch->n, fewer after a device-side failure */
     int32_t *counts;  uint8_t *wire; int64_t wire_bytes;     /* records per read, wire form */
+    int32_t  ticket;                       /* >= 0: the wire form is still on the GPU, staged for the gather (mtr_gather_stage); wire is filled by the exchange */
     /* -a only: the chains (made where the batch was resident) and the alignment paths of their records */
     int32_t  with_alignments;
     int32_t *chain_len; int32_t *chain_idx; int64_t n_chain;  /* per read: length; concatenated record indices (within the read) */
@@ -133,6 +141,8 @@ typedef struct mtrh_opts {
     size_t chunk_bytes;                    /* 0 = default */
     int   parse_threads, print_threads;    /* 0 = default */
     const char *engine_lib;                /* NULL = default (mtrh_engine_load) */
+    mtr_gather *gather;                    /* several GPUs in one process: batches leave their tables staged on the GPU for the RCCL gather (NULL: fetched to the host) */
+    int   contexts;                        /* device batches in flight per GPU: 0 = 2, or 3 where the reads are long (mean >= 8 kb: launches bound by their longest item) */
 } mtrh_opts;
 typedef struct mtrh_run mtrh_run;
 /* opens the files, plans the chunks, starts the parser threads and the device thread; NULL + message on stderr on failure */
@@ -152,6 +162,24 @@ void  mtrh_stamp(const char *what);           /* development aid: with MTR_HOST_
 void  mtrh_run_stop(mtrh_run *r);
 /* all results this rank produces for `round`, serialised one after the other (malloc'ed; free() it) */
 uint8_t *mtrh_run_round_blob(mtrh_run *r, int round, size_t *bytes);
+
+/* ---- several GPUs in ONE process: mTR -g N (multi.c) ------------------------------------------------------------------------
+ * N runs, one per GPU (its own parser threads, device thread and contexts; chunk c of the plan belongs to GPU c % N, or longest-first
+ * over the GPUs for several files), merged in output order by the calling thread.  The path's one exchange: per round the staged
+ * wire-form tables of every GPU are gathered to the first GPU over RCCL (mtr_gather_exchange) and chained + printed from there.
+ * Without RCCL (a device given twice: more ranks than GPUs; librccl missing; MTR_GATHER=host; -a, whose chains are made where the
+ * batch is resident) every GPU's tables are fetched to the host directly - same output. */
+typedef struct mtrh_multi mtrh_multi;
+typedef struct mtrh_printer mtrh_printer;
+mtrh_multi *mtrh_multi_start(const mtrh_opts *o, int n_gpus, const char *const *paths, int n_paths);
+/* every result to the printer in output order (blocks until the runs are through); 0, or -1 after an exchange failed */
+int   mtrh_multi_drain(mtrh_multi *m, mtrh_printer *p);
+/* "rccl" or "host", the number of exchanges, bytes gathered; sums of the runs' timers as mtrh_run_timing / mtrh_run_phase_times give them */
+const char *mtrh_multi_gather_mode(const mtrh_multi *m, long long *exchanges, long long *bytes);
+const char *mtrh_multi_gather_note(const mtrh_multi *m);       /* why the gather is "host" when RCCL was asked for ("" otherwise) */
+mtrh_run *mtrh_multi_run(const mtrh_multi *m, int gpu);
+int   mtrh_multi_n(const mtrh_multi *m);
+void  mtrh_multi_stop(mtrh_multi *m);
 
 /* ---- printing: chaining.cpp:125-171 (+ the alignment block of wrap_around_DP.c:187-212 with -a) --------------------- */
 typedef struct mtrh_printer mtrh_printer;

@@ -23,7 +23,8 @@
 
 typedef struct { int file; size_t begin, end; int owner, round; } chunk_t;
 /* what the device thread holds while it runs (see device_main) */
-typedef struct { mtr_ctx *ctxs[2]; mtr_file_state *fs; mtrh_result *prev; mtr_ctx *prev_ctx; int *file_ended; char *dead_msg; } device_state;
+#define MAX_CTX 3
+typedef struct { mtr_ctx *ctxs[MAX_CTX]; mtr_file_state *fs; mtrh_result *pend[MAX_CTX]; mtr_ctx *pend_ctx[MAX_CTX]; int n_pend; int *file_ended; char *dead_msg; } device_state;
 
 struct mtrh_run {
     mtrh_opts o; mtrh_engine eng;
@@ -163,7 +164,7 @@ static mtrh_result *result_new(int chunk, int file_idx, mtrh_batch *b)
 {
     mtrh_result *x = (mtrh_result *)calloc(1, sizeof *x);
     if (!x) { fprintf(stderr, "cannot allocate a result\n"); exit(EXIT_FAILURE); }
-    x->chunk = chunk; x->file_idx = file_idx; x->batch = b; x->n_report = b ? b->n : 0;
+    x->chunk = chunk; x->file_idx = file_idx; x->batch = b; x->n_report = b ? b->n : 0; x->ticket = -1;
     return x;
 }
 
@@ -240,7 +241,14 @@ static void finish_batch(mtrh_run *r, mtr_ctx *ctx, mtrh_result *x)
         n_report = x->n_report;
     } else if (st != MTR_OK) { result_fail(x, 0, r->eng.last_error(ctx)); n_report = 0; }
     x->counts = (int32_t *)calloc((size_t)n_report + 1, sizeof(int32_t));
-    if (n_report > 0) {
+    x->ticket = -1;
+    if (n_report > 0 && r->o.gather && !x->fatal && !r->o.print_alignment) {
+        /* several GPUs: the table stays on this GPU, compacted to the wire form, until the round's exchange takes it to the first GPU (multi.c) */
+        int64_t bytes = 0, total = 0; int32_t ticket = -1;
+        st = r->eng.gather_stage(r->o.gather, r->o.rank, ctx, x->counts, &total, &bytes, &ticket);
+        if (st != MTR_OK) { result_fail(x, 0, r->eng.last_error(ctx)); n_report = 0; }
+        else { x->ticket = ticket; x->wire_bytes = bytes; }
+    } else if (n_report > 0) {
         const uint8_t *blob = NULL; const int32_t *counts = NULL; int64_t bytes = 0, total = 0;
         st = r->eng.fetch_packed(ctx, x->fatal ? n_report : -1, &blob, &bytes, &counts, &total);
         if (st != MTR_OK) { result_fail(x, 0, r->eng.last_error(ctx)); n_report = 0; }
@@ -279,7 +287,7 @@ static void report_failure(mtrh_run *r, const char *msg)
         if (done) continue;
         if (stopping) break;
         mtrh_result *x = (mtrh_result *)calloc(1, sizeof *x);
-        x->chunk = c; x->file_idx = r->chunks[c].file; x->batch = (mtrh_batch *)calloc(1, sizeof(mtrh_batch)); x->last_of_chunk = 1;
+        x->chunk = c; x->file_idx = r->chunks[c].file; x->batch = (mtrh_batch *)calloc(1, sizeof(mtrh_batch)); x->last_of_chunk = 1; x->ticket = -1;
         x->counts = (int32_t *)calloc(1, sizeof(int32_t));
         x->fatal = 1; x->fatal_msg = strdup(msg);
         push_result(r, x);
@@ -301,10 +309,9 @@ static void *device_main(void *arg)
     if (setjmp(oom)) {                                   /* an allocation of this thread failed (alloc.c) */
         mtrh_oom_target = NULL;
         d = &r->dev;
-        if (d->prev && d->prev_ctx) (void)r->eng.wait(d->prev_ctx);
-        mtrh_result_free(d->prev);
+        for (int t = 0; t < d->n_pend; t++) { if (d->pend_ctx[t]) (void)r->eng.wait(d->pend_ctx[t]); mtrh_result_free(d->pend[t]); }
         if (d->fs) r->eng.fs_destroy(d->fs);
-        for (int t = 0; t < 2; t++) if (d->ctxs[t]) { (void)r->eng.wait(d->ctxs[t]); r->eng.destroy(d->ctxs[t]); }
+        for (int t = 0; t < MAX_CTX; t++) if (d->ctxs[t]) { (void)r->eng.wait(d->ctxs[t]); r->eng.destroy(d->ctxs[t]); }
         free(d->file_ended); free(d->dead_msg);
         memset(d, 0, sizeof *d);
         report_failure(r, "fatal error: cannot allocate memory");
@@ -320,17 +327,29 @@ static void *device_main(void *arg)
     return NULL;
 }
 
+/* the batches in flight, oldest first: everything before a failure is reported first, like the reference */
+static void finish_oldest(mtrh_run *r, device_state *d)
+{
+    mtrh_result *x = d->pend[0]; mtr_ctx *c = d->pend_ctx[0];
+    for (int t = 1; t < d->n_pend; t++) { d->pend[t - 1] = d->pend[t]; d->pend_ctx[t - 1] = d->pend_ctx[t]; }
+    d->n_pend--;
+    d->pend[d->n_pend] = NULL; d->pend_ctx[d->n_pend] = NULL;
+    finish_batch(r, c, x);
+}
+static void finish_all(mtrh_run *r, device_state *d) { while (d->n_pend > 0) finish_oldest(r, d); }
+
 #define ctxs (d->ctxs)
 #define fs (d->fs)
-#define prev (d->prev)
-#define prev_ctx (d->prev_ctx)
 #define file_ended (d->file_ended)
 #define dead_msg (d->dead_msg)
 static void device_body(mtrh_run *r, device_state *d)
 {
-    /* Two contexts = two device batches in flight.  The second one is created when a second batch shows up. */
+    /* nctx contexts = nctx device batches in flight (a context is created when a batch needs it).  Two keep the chip busy on reads of a few kb:
+     * the launches are bound by instruction issue.  Launches of LONG reads (config 3's 42 kb) are bound by their longest work items - a 40 000-row
+     * alignment is one wavefront's serial chain - and leave most of the chip idle behind them: a third batch in flight fills it ([measured, MI355X]
+     * 100 reads of 42 kb per batch: 78.5 ms a step with two contexts, 53.8 with three, 51.4 with four). */
     int fs_file = -1;
-    int k = 0, dead = 0;
+    int k = 0, dead = 0, nctx = r->o.contexts > 0 ? (r->o.contexts > MAX_CTX ? MAX_CTX : r->o.contexts) : 0;
     file_ended = (int *)calloc((size_t)r->n_files + 1, sizeof(int));
     for (int idx = 0; idx < r->n_list; idx++) {
         double t0 = now_s();
@@ -338,7 +357,7 @@ static void device_body(mtrh_run *r, device_state *d)
         while (!r->pstate[idx] && !r->stopping && !r->parse_failed) pthread_cond_wait(&r->cv_parse, &r->mu);
         if (!r->pstate[idx] && r->parse_failed && !r->stopping) {
             pthread_mutex_unlock(&r->mu);
-            if (prev) { finish_batch(r, prev_ctx, prev); prev = NULL; }       /* what is on the device is reported first */
+            finish_all(r, d);                                    /* what is on the device is reported first */
             mtrh_oom(0);
         }
         mtrh_batch *b = r->parsed[idx]; r->parsed[idx] = NULL;
@@ -373,20 +392,25 @@ static void device_body(mtrh_run *r, device_state *d)
                 if (file_ended[c->file] && !dead) { x->n_report = 0; b->end = MTRH_END_NONE; }
                 if (!x->counts) x->counts = (int32_t *)calloc((size_t)x->n_report + 1, sizeof(int32_t));
                 if (b->n == 0) x->n_report = 0;
-                if (prev) { finish_batch(r, prev_ctx, prev); prev = NULL; }
+                finish_all(r, d);
                 if (b->end != MTRH_END_NONE) file_ended[c->file] = 1;
                 push_result(r, x);
                 b = nx;
                 continue;
             }
             t0 = now_s();
-            mtr_ctx **pc = &ctxs[k & 1];
+            if (nctx == 0) {                                     /* decided by the first batch that runs */
+                int64_t bases = 0;
+                for (int i = 0; i < b->n; i++) bases += b->lens[i];
+                nctx = bases / (b->n > 0 ? b->n : 1) >= 8000 ? 3 : 2;
+            }
+            mtr_ctx **pc = &ctxs[k % nctx];
             mtr_status st = MTR_OK;
             if (!*pc) {
                 const double tc = now_s();
                 st = r->eng.create(r->o.device, r->o.manhattan, r->o.min_match_ratio, pc);
                 pthread_mutex_lock(&r->mu); r->t_create += now_s() - tc; pthread_mutex_unlock(&r->mu);
-                mtrh_stamp(k == 0 ? "first device context created" : "second device context created");
+                mtrh_stamp(k == 0 ? "first device context created" : k == 1 ? "second device context created" : "third device context created");
                 if (st != MTR_OK) {
                     char m[256];
                     snprintf(m, sizeof m, "fatal error: no usable HIP device (mtr_create returned %d); this build has no CPU path", (int)st);
@@ -403,30 +427,29 @@ static void device_body(mtrh_run *r, device_state *d)
             free(b->packed); b->packed = NULL;
             pthread_mutex_lock(&r->mu); r->t_submit += now_s() - t0; pthread_mutex_unlock(&r->mu);
             if (k < 2) mtrh_stamp(k == 0 ? "first batch uploaded and launched" : "second batch uploaded and launched");
-            if (prev) { finish_batch(r, prev_ctx, prev); prev = NULL; }       /* like the reference: everything before a failure is reported first */
             if (dead) {
+                finish_all(r, d);                                /* like the reference: everything before a failure is reported first */
                 x->counts = (int32_t *)calloc(1, sizeof(int32_t));
                 result_fail(x, 0, dead_msg);
                 push_result(r, x);
             } else {
                 if (b->end != MTRH_END_NONE) file_ended[c->file] = 1;
-                prev = x; prev_ctx = *pc; k++;
+                d->pend[d->n_pend] = x; d->pend_ctx[d->n_pend] = *pc; d->n_pend++; k++;
+                while (d->n_pend > nctx - 1) finish_oldest(r, d);       /* the batch just launched stays in flight (with three contexts: the one before it too) */
             }
             b = nx;
         }
     }
-    if (prev) { finish_batch(r, prev_ctx, prev); prev = NULL; }
+    finish_all(r, d);
     mtrh_stamp("last batch fetched");
     if (fs) r->eng.fs_destroy(fs);
-    for (int t = 0; t < 2; t++) if (ctxs[t]) r->eng.destroy(ctxs[t]);
+    for (int t = 0; t < MAX_CTX; t++) if (ctxs[t]) r->eng.destroy(ctxs[t]);
     mtrh_stamp("device contexts destroyed");
     free(file_ended); free(dead_msg);
     memset(d, 0, sizeof *d);
 }
 #undef ctxs
 #undef fs
-#undef prev
-#undef prev_ctx
 #undef file_ended
 #undef dead_msg
 

@@ -85,6 +85,7 @@ mtrh_result *mtrh_result_deserialize(const uint8_t *blob, size_t bytes, size_t *
         if (need != (size_t)h[H_BYTES]) return NULL;
     }
     mtrh_result *r = (mtrh_result *)calloc(1, sizeof *r);
+    r->ticket = -1;
     mtrh_batch *b = (mtrh_batch *)calloc(1, sizeof *b);
     r->batch = b;
     r->chunk = (int32_t)h[H_CHUNK]; r->file_idx = (int32_t)h[H_FILE]; r->last_of_chunk = (int32_t)h[H_LAST];

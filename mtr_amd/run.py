@@ -35,7 +35,7 @@ class Opts(C.Structure):
     _fields_ = [("print_alignment", C.c_int), ("manhattan", C.c_int), ("file_order", C.c_int), ("device", C.c_int),
                 ("min_match_ratio", C.c_float), ("rank", C.c_int), ("world", C.c_int), ("lpt", C.c_int),
                 ("chunk_bytes", C.c_size_t), ("parse_threads", C.c_int), ("print_threads", C.c_int),
-                ("engine_lib", C.c_char_p)]
+                ("engine_lib", C.c_char_p), ("gather", C.c_void_p), ("contexts", C.c_int)]
 
 
 def load_host():

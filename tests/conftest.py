@@ -23,7 +23,7 @@ def pytest_configure(config):
 # Evidence cheapest-first: the in-process parity files, then the stage-level ones, then the command line, and the
 # multi-process tests (launcher, torchrun, RCCL) last - a plumbing failure must never stand between `pytest -x` and the parity tests.
 _FILE_ORDER = ["test_gpu_parity.py", "test_gpu_stages.py", "test_gpu_cli.py", "test_gpu_multi.py"]
-_LAST_IN_FILE = ("launcher", "rccl", "bench_strong")          # inside test_gpu_multi.py: in-process tests before the ones that start ranks
+_LAST_IN_FILE = ("launcher", "rccl", "bench_strong", "c_host")          # inside test_gpu_multi.py: in-process tests before the ones that start ranks
 
 
 def pytest_collection_modifyitems(session, config, items):

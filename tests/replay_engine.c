@@ -196,3 +196,71 @@ mtr_status mtr_alignments(mtr_ctx *c, int32_t n, const int32_t *read_idx, const 
     *out_ops = ops; *out_off = off; *out_end = ends;
     return MTR_OK;
 }
+
+/* ---- the multi-GPU gather of include/mtr_hip.h (ABI 5), replayed in host memory: same tickets, same lifetimes, no device.  MTR_REPLAY_DEVICES = how many
+ * "GPUs" the stand-in reports (default 8); MTR_REPLAY_GATHER_FAIL=1 makes mtr_gather_create fail as it does where RCCL cannot be used, so that the host's
+ * fall-back to mtr_fetch_results_packed is exercised as well. */
+#include <pthread.h>
+#define RG_SLOTS 1024
+typedef struct { uint8_t *p; int64_t bytes; int busy; } rg_slot;
+struct mtr_gather { int n; rg_slot *slots; pthread_mutex_t mu; uint8_t *host; size_t host_cap; char err[128]; long long exchanges; };
+
+mtr_status mtr_device_count(int32_t *out) { if (!out) return MTR_ERR_BAD_ARG; const char *e = getenv("MTR_REPLAY_DEVICES"); *out = e ? atoi(e) : 8; return *out > 0 ? MTR_OK : MTR_ERR_NO_DEVICE; }
+const char *mtr_gather_last_error(const mtr_gather *g) { return g ? g->err : "no gather"; }
+mtr_status mtr_gather_create(int32_t n, const int32_t *devices, mtr_gather **out)
+{
+    if (!out || n <= 0 || !devices) return MTR_ERR_BAD_ARG;
+    mtr_gather *g = (mtr_gather *)calloc(1, sizeof *g);
+    *out = g;
+    if (getenv("MTR_REPLAY_GATHER_FAIL")) { snprintf(g->err, sizeof g->err, "replayed failure: no RCCL here"); return MTR_ERR_NO_DEVICE; }
+    for (int r = 0; r < n; r++) for (int q = 0; q < r; q++) if (devices[q] == devices[r]) { snprintf(g->err, sizeof g->err, "device %d is given to two ranks", devices[r]); return MTR_ERR_NO_DEVICE; }
+    g->n = n; g->slots = (rg_slot *)calloc((size_t)n * RG_SLOTS, sizeof(rg_slot));
+    pthread_mutex_init(&g->mu, NULL);
+    return MTR_OK;
+}
+void mtr_gather_destroy(mtr_gather *g)
+{
+    if (!g) return;
+    if (g->slots) { for (int i = 0; i < g->n * RG_SLOTS; i++) free(g->slots[i].p); free(g->slots); pthread_mutex_destroy(&g->mu); }
+    free(g->host); free(g);
+}
+mtr_status mtr_gather_stage(mtr_gather *g, int32_t rank, mtr_ctx *c, int32_t *counts_host, int64_t *out_total, int64_t *out_bytes, int32_t *out_ticket)
+{
+    if (!g || !c || !counts_host || !out_total || !out_bytes || !out_ticket || rank < 0 || rank >= g->n) return MTR_ERR_BAD_ARG;
+    { mtr_status w = mtr_wait(c); if (w != MTR_OK) return w; }
+    const uint8_t *blob; int64_t bytes, total; const int32_t *counts;
+    mtr_status st = mtr_fetch_results_packed(c, -1, &blob, &bytes, &counts, &total);
+    if (st != MTR_OK) return st;
+    memcpy(counts_host, counts, sizeof(int32_t) * (size_t)c->n);
+    pthread_mutex_lock(&g->mu);
+    int slot = -1;
+    for (int i = 0; i < RG_SLOTS && slot < 0; i++) if (!g->slots[rank * RG_SLOTS + i].busy) slot = i;
+    if (slot < 0) { pthread_mutex_unlock(&g->mu); return MTR_ERR_OVERFLOW; }
+    rg_slot *s = &g->slots[rank * RG_SLOTS + slot];
+    s->busy = 1; s->bytes = bytes; free(s->p); s->p = (uint8_t *)malloc((size_t)bytes + 8); memcpy(s->p, blob, (size_t)bytes);
+    pthread_mutex_unlock(&g->mu);
+    *out_total = total; *out_bytes = bytes; *out_ticket = rank * RG_SLOTS + slot;
+    return MTR_OK;
+}
+mtr_status mtr_gather_exchange(mtr_gather *g, int32_t n, const int32_t *tickets, const uint8_t **out_ptrs, int64_t *out_bytes)
+{
+    if (!g || n < 0 || (n > 0 && (!tickets || !out_ptrs || !out_bytes))) return MTR_ERR_BAD_ARG;
+    size_t total = 0;
+    pthread_mutex_lock(&g->mu);
+    for (int i = 0; i < n; i++) {
+        if (tickets[i] < 0 || tickets[i] >= g->n * RG_SLOTS || !g->slots[tickets[i]].busy) { pthread_mutex_unlock(&g->mu); snprintf(g->err, sizeof g->err, "ticket %d names no staged table", tickets[i]); return MTR_ERR_BAD_ARG; }
+        total += ((size_t)g->slots[tickets[i]].bytes + 255) & ~(size_t)255;
+    }
+    if (g->host_cap < total + 8) { free(g->host); g->host_cap = total + total / 4 + 4096; g->host = (uint8_t *)malloc(g->host_cap); }
+    size_t off = 0;
+    for (int i = 0; i < n; i++) {
+        rg_slot *s = &g->slots[tickets[i]];
+        memcpy(g->host + off, s->p, (size_t)s->bytes);
+        out_ptrs[i] = g->host + off; out_bytes[i] = s->bytes;
+        off += ((size_t)s->bytes + 255) & ~(size_t)255;
+        s->busy = 0;
+    }
+    g->exchanges++;
+    pthread_mutex_unlock(&g->mu);
+    return MTR_OK;
+}

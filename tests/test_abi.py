@@ -30,7 +30,7 @@ def test_exports_every_declared_symbol(lib):
     assert len(declared) >= 30
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/ but not exported by libmtr_hip.so"
-    assert lib.mtr_abi_version() == 4
+    assert lib.mtr_abi_version() == 5
 
 
 def test_record_layout_matches_header():

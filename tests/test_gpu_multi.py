@@ -66,6 +66,140 @@ def test_packed_upload_equals_byte_upload(eng):
     assert eng.fetch() == want
 
 
+# ---- several GPUs in ONE process: the C host (mTR -g N, mtr_amd/host/multi.c) and the RCCL gather of the C-ABI (mtr_gather_*) ------------
+def _mtr_g(args, env_extra=None):
+    exe = os.path.join(ROOT, "mtr_amd", "host", "mTR")
+    subprocess.run(["make", "-s", "-C", os.path.dirname(exe), "mTR"], check=True)
+    env = {k: v for k, v in os.environ.items() if k not in ("MTR_LIB", "MTR_REPLAY_TABLE", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
+    env.update(env_extra or {})
+    return subprocess.run([exe, *args], capture_output=True, env=env, timeout=900, cwd=ROOT)
+
+
+def _gather_line(p):
+    lines = [ln for ln in p.stderr.decode().splitlines() if "\tgather " in ln]
+    assert len(lines) == 1, p.stderr.decode()[-800:]
+    return lines[0]
+
+
+def test_gather_api_moves_the_wire_form_through_rccl(eng):
+    """mtr_gather_stage + mtr_gather_exchange (ncclCommInitAll, ncclSend / ncclRecv in one group, one copy to pinned host memory) against
+    mtr_fetch_results_packed of the same batches.  One GPU here: with MTR_GATHER_SELF=1 the first GPU's own tables go through ncclSend / ncclRecv to
+    itself, so RCCL's point-to-point path runs on the one-GPU box; without it they take the local copy.  Several batches per exchange, slots reused."""
+    import ctypes as C
+    lib = eng.lib
+    n = C.c_int32()
+    assert lib.mtr_device_count(C.byref(n)) == 0 and n.value >= 1
+    lib.mtr_gather_last_error.restype = C.c_char_p
+    batches = [[c for _, c in synth.make_reads("c4", 300, 70 + k)] for k in range(3)]
+    want = []
+    for b in batches:
+        eng.process(b)
+        want.append(eng.fetch_packed())
+    for self_send in ("1", "0"):
+        os.environ["MTR_GATHER_SELF"] = self_send
+        try:
+            g = C.c_void_p()
+            dev = (C.c_int32 * 1)(0)
+            st = lib.mtr_gather_create(1, dev, C.byref(g))
+            assert st == 0, lib.mtr_gather_last_error(g)
+        finally:
+            del os.environ["MTR_GATHER_SELF"]
+        e2 = mtr_amd.Engine()
+        for rounds in range(2):                                    # the second round reuses the staging slots and the buffers
+            tickets = []
+            for b, (data, counts) in zip(batches, want):
+                e = eng if len(tickets) % 2 == 0 else e2
+                e.upload(b); e.run()
+                cnt = (C.c_int32 * len(b))()
+                total, nbytes, ticket = C.c_int64(), C.c_int64(), C.c_int32()
+                assert lib.mtr_gather_stage(g, 0, e.h, cnt, C.byref(total), C.byref(nbytes), C.byref(ticket)) == 0
+                assert list(cnt) == counts.tolist() and nbytes.value == len(data) and total.value == int(counts.sum())
+                tickets.append(ticket.value)
+            assert len(set(tickets)) == len(tickets)
+            ptrs = (C.c_void_p * len(tickets))()
+            sizes = (C.c_int64 * len(tickets))()
+            tk = (C.c_int32 * len(tickets))(*tickets)
+            st = lib.mtr_gather_exchange(g, len(tickets), tk, ptrs, sizes)
+            assert st == 0, lib.mtr_gather_last_error(g)
+            for i, (data, _) in enumerate(want):
+                assert sizes[i] == len(data) and C.string_at(ptrs[i], sizes[i]) == data, (self_send, rounds, i)
+            assert lib.mtr_gather_exchange(g, len(tickets), tk, ptrs, sizes) != 0          # the tickets were released
+        e2.close()
+        lib.mtr_gather_destroy(g)
+    # a device given twice is refused with a reason (the host then fetches every GPU's tables directly)
+    g = C.c_void_p()
+    dev = (C.c_int32 * 2)(0, 0)
+    assert lib.mtr_gather_create(2, dev, C.byref(g)) != 0 and b"two ranks" in lib.mtr_gather_last_error(g)
+    lib.mtr_gather_destroy(g)
+
+
+@pytest.mark.timeout(1800)
+def test_c_host_over_gpus_config4_and_config5():
+    """mTR -g N, the C host of the multi-GPU path (one process, a run per GPU, RCCL called directly): BASELINE config 4 (one file) and config 5 (the 15
+    bundled files, -p) with as many GPUs as are visible through RCCL (on a one-GPU box: -g 1 with the tables sent to the GPU itself through
+    ncclSend / ncclRecv), and with 2 and 4 runs sharing the card (every run's tables fetched to the host) - stdout byte-identical to the goldens"""
+    import torch
+    n = torch.cuda.device_count()
+    files = [gu.input_path(nm) for nm in BUNDLED]
+    for g, extra, mode in [(n, {"MTR_GATHER": "rccl", "MTR_GATHER_SELF": "1"}, "rccl"), (2 * n, {}, "host"), (4 * n, {}, "host")]:
+        p = _mtr_g(["-c", "-g", str(g), gu.input_path("synth_c4")], dict(extra, MTR_CHUNK_BYTES="20000"))
+        assert p.returncode == 0, p.stderr.decode()[-800:]
+        assert p.stdout == golden("synth_c4", "default"), (g, mode)
+        line = _gather_line(p)
+        assert line.startswith(f"{g} GPUs\tgather {mode}, "), line
+        if mode == "rccl":
+            assert " 0 exchange" not in line
+        p = _mtr_g(["-p", "-c", "-g", str(g), *files], extra)
+        assert p.returncode == 0, p.stderr.decode()[-800:]
+        assert p.stdout == b"".join(golden(nm, "p") for nm in BUNDLED), (g, mode)
+        assert f"gather {mode}" in _gather_line(p)
+
+
+@pytest.mark.timeout(1800)
+def test_c_host_over_gpus_alignments_file_order_and_a_failing_read(tmp_path):
+    import torch
+    n = torch.cuda.device_count()
+    p = _mtr_g(["-a", "-g", str(2 * n), gu.input_path("synth_c2")], {"MTR_CHUNK_BYTES": "30000"})
+    assert p.returncode == 0 and p.stdout == golden("synth_c2", "a"), p.stderr.decode()[-800:]
+    from tests.oracle_binding import ORACLE_DIR
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "oracle"], check=True)
+    fa = os.path.join(gu.GOLDEN, "file_order", "mixed_lengths.fa")
+    want = subprocess.run([os.path.join(ORACLE_DIR, "mtr_oracle_cli"), "-B", fa], capture_output=True, check=True).stdout
+    for g, extra in ((n, {"MTR_GATHER": "rccl", "MTR_GATHER_SELF": "1"}), (3 * n, {})):
+        p = _mtr_g(["-B", "-g", str(g), fa], dict(extra, MTR_CHUNK_BYTES="15000"))
+        assert p.returncode == 0 and p.stdout == want, (g, p.stderr.decode()[-800:])
+    # a read whose DP exceeds the (lowered) WrapDPsize, on a GPU other than the first: the reads before it are printed, then the reference's message
+    rng = np.random.RandomState(64)
+    reads = [synth.make_read(rng, 12, 14, 100, 100)[0] for _ in range(12)] + [c for _, c in synth.make_reads("headline2k", 3, 65)] + [synth.make_read(rng, 5, 30, 10, 10)[0]]
+    fb = tmp_path / "fails.fa"
+    synth.write_fasta(str(fb), [(f"read{i}", c) for i, c in enumerate(reads)])
+    env = {"MTR_TEST_WRAP_DP_SIZE": "40000"}
+    o = subprocess.run([os.path.join(ORACLE_DIR, "mtr_oracle_cli"), str(fb)], capture_output=True, env=dict(os.environ, **env))
+    assert o.returncode != 0 and b"WrapDPsize" in o.stderr and o.stdout.count(b"\n") >= 5
+    for g, extra in ((n, {"MTR_GATHER": "rccl", "MTR_GATHER_SELF": "1"}), (2 * n, {})):
+        p = _mtr_g(["-g", str(g), str(fb)], dict(extra, MTR_CHUNK_BYTES="2500", **env))
+        assert p.returncode != 0 and b"WrapDPsize" in p.stderr, (g, p.stderr.decode()[-500:])
+        assert p.stdout == o.stdout, g
+
+
+@pytest.mark.timeout(1800)
+def test_c_host_rccl_config4_ten_thousand_reads_against_the_oracles_hash(tmp_path):
+    """10 000 config-4 reads through mTR -g <GPUs> with the RCCL gather: the record stream is not visible on stdout, so the check is the report itself -
+    identical to the single-GPU command line's (whose records are checked read by read elsewhere) - plus several rounds of real size (3 MB each)"""
+    import torch
+    n = torch.cuda.device_count()
+    fa = tmp_path / "c4_10k.fa"
+    synth.write_fasta(str(fa), [(str(i), c) for i, c in enumerate(c for _, c in synth.make_reads("c4", 10000, 44))])
+    one = _mtr_g([str(fa)])
+    assert one.returncode == 0 and one.stdout.count(b"\n") > 10000
+    p = _mtr_g(["-c", "-g", str(n), str(fa)], {"MTR_GATHER": "rccl", "MTR_GATHER_SELF": "1", "MTR_CHUNK_BYTES": str(4 << 20)})
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    assert p.stdout == one.stdout
+    line = _gather_line(p)
+    assert "gather rccl" in line and int(line.split(" exchange")[0].split()[-1]) >= 4 // n, line
+
+
 def _run(args, world, backend=None):
     cmd = [sys.executable, "-m", "mtr_amd.run", "--stats"] + (["--gpus", str(world)] if world > 1 else []) + (["--backend", backend] if backend else []) + args
     env = {k: v for k, v in os.environ.items() if k not in ("MTR_LIB", "MTR_REPLAY_TABLE", "RANK", "WORLD_SIZE", "LOCAL_RANK")}

@@ -15,6 +15,10 @@ the fetch of step s overlaps the kernels of step s+1, as in the host pipeline (m
   value          reads/s at the boundary (above);            value_kernel  the same steps without the fetch (round 1's figure)
   value_cli      reads/s of the command line mtr_amd/host/mTR on a FASTA of the same reads, wall clock incl. process
                  start, HIP initialisation, parsing, chaining and printing (N = 1 only; NOT resident inputs)
+  value_with_upload  the steps with a FRESH batch each, handed over as host buffers: 2-bit packing + copy to the device inside
+                 the step (N = 1; PCIe-inclusive, never `value`)
+  value_launcher reads/s of the multi-GPU PRODUCT path: mTR -g N (the C host, one process, RCCL gather) on a FASTA of 100 000
+                 reads, wall clock incl. process start, HIP + RCCL initialisation, parsing, chaining and printing
 With N GPUs (weak scaling) every rank holds its own 10 000 reads and the step ends with the ONE exchange of the path: the
 wire-form tables go device-to-device to rank 0 over RCCL (mtr_export_packed_device + gather).  --strong c4: BASELINE
 config 4 — one set of 100 000 mixed-unit reads, contiguous blocks balanced by sum of lengths; rank 0 checks the sha256 of
@@ -169,6 +173,38 @@ def cli_rate(reads, n, flags=()):
     return {"reads": n, "seconds": best, "reads_per_s": n / best, "stamps_s": stamps}
 
 
+def launcher_rate(reads, n_total, n_gpus, force_rccl=False):
+    """wall clock of the multi-GPU PRODUCT path - mtr_amd/host/mTR -g N (one process, a run per GPU, the record tables gathered to the first GPU over
+    RCCL, chained and printed there) - on a FASTA of n_total reads, process start, HIP / RCCL initialisation, parsing and printing included; best of 2"""
+    from mtr_amd import synth
+
+    exe = os.path.join(ROOT, "mtr_amd", "host", "mTR")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(exe), "mTR"], check=True)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MTR_LIB")}
+    env.update(MTR_HOST_TIMING="1", GPU_MAX_HW_QUEUES="8")
+    if force_rccl:      # every round over RCCL: the job waits for librccl + ncclCommInitAll before its first batch (on one GPU the tables go to the GPU itself)
+        env.update(MTR_GATHER="rccl", MTR_GATHER_SELF="1")
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, "reads.fa")
+        synth.write_fasta(fa, [(str(i), reads[i % len(reads)]) for i in range(n_total)])
+        best, gather, err = None, None, None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            try:
+                p = subprocess.run([exe, "-c", "-g", str(n_gpus), fa], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, timeout=600)
+            except subprocess.TimeoutExpired:
+                return {"error": "timeout after 600 s"}
+            dt = time.perf_counter() - t0
+            if p.returncode != 0:
+                return {"error": p.stderr.decode(errors="replace")[-300:]}
+            if best is None or dt < best:
+                best = dt
+                gather = [ln for ln in p.stderr.decode(errors="replace").splitlines() if "\tgather " in ln]
+    return {"command": f"mTR -c -g {n_gpus} <fasta of {n_total} reads> > /dev/null", "reads": n_total, "gpus": n_gpus, "seconds": best, "reads_per_s": n_total / best,
+            "gather": gather[0] if gather else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,7 +272,11 @@ def main():
     # between them, so the kernels of step s+1 are enqueued while step s is fetched (and while its last wavefronts finish:
     # a read is one wavefront's serial chain).  Every step does all of its work.  With an exchange step (N > 1) one more
     # context, so that the next kernel is already enqueued while the host waits for the gather of the previous step.
-    NCTX = int(os.environ.get("MTR_BENCH_CONTEXTS", "3" if dist_on else "2"))
+    # --strong: ONE data set is the whole job, so a step is the whole job - kernels, then the gather, then the copy to the host, one after the other on
+    # one context (repetitions of a job do not overlap each other; round 4 pipelined them and measured the next repetition's persistent kernels holding
+    # the wavefront slots the gather's kernels were waiting for: 687 ms a step for a 335 ms launch).  Config 3: three batches in flight, as the host
+    # pipeline runs long reads (launches bound by their longest work items leave most of the chip idle: 78.5 ms a step with two, 53.8 with three).
+    NCTX = int(os.environ.get("MTR_BENCH_CONTEXTS", "1" if a.strong else "3" if (dist_on or a.config == "c3") else "2"))
     engs = [mtr_amd.Engine(device=local_rank) for _ in range(NCTX)]
     for e in engs:
         e.upload(reads)                                 # inputs resident in HBM before the timed region
@@ -300,11 +340,12 @@ def main():
         out = out_bufs[i] if rank == 0 else None
         if os.environ.get("MTR_BENCH_XMODE") == "export" and not keep:
             pass
-        elif backend == "nccl" and not keep:
+        elif backend == "nccl" and not keep and not a.strong:
             works[i] = dist.gather(pad, out, dst=0, async_op=True)
         else:
             dist.gather(pad, out, dst=0)
             to_host(i)
+            torch.cuda.current_stream().synchronize()
         tdbg.append(time.perf_counter())
         if os.environ.get("MTR_BENCH_DEBUG") and rank == 0:
             print("exchange step", s, "ms: wait prev gather %.2f, buffers %.2f, export %.2f, sizes+gather enqueue %.2f" %
@@ -343,7 +384,7 @@ def main():
         k2 = []
         sync()
         t0 = time.perf_counter()
-        depth = NCTX - 1                                # steps enqueued ahead of the one being finished
+        depth = max(NCTX - 1, 0)                        # steps enqueued ahead of the one being finished
         for s in range(min(depth, steps)):
             engs[s % NCTX].run_async()
         for s in range(steps):
@@ -500,7 +541,8 @@ def main():
                           "forced_on_one_rank": world == 1} if dist_on else None),
             "config": {"workload": workload, "reads_per_gpu": n_local,
                        "parallelism": f"reads sharded over {world} GPU(s), wire-form record tables gathered to rank 0" if world > 1
-                                      else "1 GPU, record tables fetched to pinned host memory in wire form"},
+                                      else "1 GPU, record tables fetched to pinned host memory in wire form",
+                       "batches_in_flight": NCTX},
             "value_definition": "steps end with the record tables in host memory (wire form, mtr_fetch_results_packed)" if not dist_on
                                 else "steps end with the record tables of every rank in rank 0's pinned host memory (wire form: RCCL gather to rank 0's GPU, one copy to the host)",
             "ms_per_read": dt / a.steps * 1e3 / max(n_job, 1),
@@ -599,6 +641,10 @@ def main():
             out["value_cli"] = c10.get("reads_per_s")
             out["cli"] = {"note": "mtr_amd/host/mTR <fasta> > /dev/null, wall clock incl. process start and HIP initialisation; best of 3",
                           "one_batch": c1, "ten_batches": c10, "empty_hip_program": empty_hip_program()}
+            lr = launcher_rate(reads, 10 * len(reads), 1)
+            out["launcher"] = lr
+            out["value_launcher"] = lr.get("reads_per_s")
+            out["launcher_rccl_forced"] = launcher_rate(reads, 10 * len(reads), 1, force_rccl=True)
             try:        # the command line's own part: from the first device context (the runtime is up) to the end of the run
                 st = c10["stamps_s"]
                 own = st["run stopped"] - st["first device context created"]
@@ -631,9 +677,21 @@ def main():
                 sec = {"error": "timeout after 420 s: " + ((ex.stderr or b"")[-300:].decode(errors="replace") if isinstance(ex.stderr, bytes) else str(ex.stderr or "")[-300:])}
             sec["wall_s"] = time.perf_counter() - t0
             out["secondary"] = {"c3": sec}
-        print(json.dumps(out))
     for e in engs:
         e.close()
+    engs.clear()
+    if world > 1 and not a.strong and a.config is None and not a.no_cli:
+        # what users run on N GPUs: the C command line with -g N on 100 000 reads, wall clock incl. start-up.  Every rank has given its GPU memory back;
+        # rank 0 starts the command (a child process: it touches every GPU itself), the others wait.
+        torch.cuda.empty_cache()
+        dist.barrier()
+        if rank == 0:
+            lr = launcher_rate(reads, 100000, world)
+            out["launcher"] = lr
+            out["value_launcher"] = lr.get("reads_per_s")
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out))
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -174,9 +174,8 @@ int64_t    mtr_pack_records(const mtr_record *records, int64_t n_records, uint8_
  *                        host memory owned by the gather, valid until the next exchange; the tickets are released.  One
  *                        caller at a time.  Tables of the first GPU itself skip the collective (MTR_GATHER_SELF=1 sends
  *                        them through ncclSend/ncclRecv to itself as well: the RCCL path on a one-GPU box).
- * devices[] must be distinct (RCCL refuses a device twice); librccl.so is bound at run time by mtr_gather_create and only
- * there, so a single-GPU process never loads it.  MTR_ERR_NO_DEVICE: RCCL missing / communicator not created (the text is
- * in mtr_gather_last_error); a host that gets it fetches every GPU's tables with mtr_fetch_results_packed instead. */
+ * librccl.so is bound at run time by mtr_gather_create and only there, so a single-GPU process never loads it; RCCL needs
+ * devices[] distinct (it takes a device once per communicator) - a gather over repeated devices works through the host copies. */
 typedef struct mtr_gather mtr_gather;
 mtr_status mtr_device_count(int32_t *out_count);
 mtr_status mtr_gather_create(int32_t n_ranks, const int32_t *devices, mtr_gather **out);
@@ -185,6 +184,14 @@ const char *mtr_gather_last_error(const mtr_gather *g);
 mtr_status mtr_gather_stage(mtr_gather *g, int32_t rank, mtr_ctx *ctx, int32_t *counts_host, int64_t *out_total_records,
                             int64_t *out_bytes, int32_t *out_ticket);
 mtr_status mtr_gather_exchange(mtr_gather *g, int32_t n_tickets, const int32_t *tickets, const uint8_t **out_ptrs, int64_t *out_bytes);
+/* RCCL comes up in the background (loading librccl.so + ncclCommInitAll: ~2 s on an MI355X box, more than a 100 000-read job takes): mtr_gather_create
+ * returns at once, and an exchange that finds RCCL not up yet - or not usable: librccl missing, a device given twice - copies its tables from every GPU's
+ * staging buffer straight into the pinned host buffer instead; the results are the same.  mtr_gather_wait_ready blocks until RCCL is up (MTR_OK) or known
+ * to be unusable (MTR_ERR_NO_DEVICE, reason in mtr_gather_last_error).  mtr_gather_get_stats: out[0] exchanges over RCCL, [1] exchanges straight to the host,
+ * [2] / [3] their bytes, [4] ms RCCL took to come up, [5] 1 = up, 0 = still coming up, -1 = not usable.  mtr_gather_destroy does not wait for a library
+ * that is still coming up: it leaves the object to the process's end, and such a process should leave through _exit. */
+mtr_status mtr_gather_wait_ready(mtr_gather *g);
+mtr_status mtr_gather_get_stats(const mtr_gather *g, int64_t *out, int32_t n);
 
 /* File-order mode = the reference's own behaviour on a multi-read file (leak A, and H2) instead of
  * isolated semantics.  The reference's inputString_w_rand and orgInputString live for the whole file

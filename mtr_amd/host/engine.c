@@ -47,6 +47,7 @@ int mtrh_engine_load(mtrh_engine *e, const char *lib_path, char *err, size_t err
     BIND(fs_create, "mtr_file_state_create"); BIND(fs_destroy, "mtr_file_state_destroy"); BIND(fs_skip, "mtr_file_state_skip");
     BIND(device_count, "mtr_device_count"); BIND(gather_create, "mtr_gather_create"); BIND(gather_destroy, "mtr_gather_destroy");
     BIND(gather_last_error, "mtr_gather_last_error"); BIND(gather_stage, "mtr_gather_stage"); BIND(gather_exchange, "mtr_gather_exchange");
+    BIND(gather_wait_ready, "mtr_gather_wait_ready"); BIND(gather_get_stats, "mtr_gather_get_stats");
     __typeof__(mtr_abi_version) *ver = NULL;
     *(void **)(&ver) = dlsym(e->dl, "mtr_abi_version");
     if (!ver || ver() != MTR_ABI_VERSION) {

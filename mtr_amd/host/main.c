@@ -87,12 +87,10 @@ int main(int argc, char **argv)
         for (int i = 0; i < MTR_N_KERNEL_TIMES; i++) ph[i] += p8[i];
         if (g == 0) snprintf(engine_path, sizeof engine_path, "%s", mtrh_run_engine_path(rg));
     }
+    int leave_fast = 0;
     if (multi) {
-        long long nx = 0, nb = 0;
-        const char *mode = mtrh_multi_gather_mode(multi, &nx, &nb);
-        snprintf(gather_line, sizeof gather_line, "%d GPUs\tgather %s, %lld exchange(s), %lld bytes of record tables%s%s%s", mtrh_multi_n(multi), mode, nx, nb,
-                 mtrh_multi_gather_note(multi)[0] ? " (" : "", mtrh_multi_gather_note(multi), mtrh_multi_gather_note(multi)[0] ? ")" : "");
-        mtrh_multi_stop(multi);
+        mtrh_multi_gather_line(multi, gather_line, sizeof gather_line);
+        leave_fast = mtrh_multi_stop(multi);
     } else mtrh_run_stop(run);
     mtrh_stamp("run stopped");
     if (getenv("MTR_HOST_TIMING"))                /* development aid: phase times on stderr */
@@ -121,6 +119,10 @@ int main(int argc, char **argv)
         fprintf(stderr, "\t%i\tCount of queries\n", (int)queries);
         fprintf(stderr, "%s\tengine library%s\n", engine_path, getenv("MTR_LIB") ? " (from $MTR_LIB)" : "");   /* this build: what computed the records */
         if (gather_line[0]) fprintf(stderr, "%s\n", gather_line);                 /* this build, -g N: how the tables reached the printer */
+    }
+    if (leave_fast) {                             /* RCCL is still coming up on its thread (a job shorter than the library's start-up): no teardown under it */
+        fflush(stdout); fflush(stderr);
+        _exit(status ? EXIT_FAILURE : EXIT_SUCCESS);
     }
     return status ? EXIT_FAILURE : EXIT_SUCCESS;
 }

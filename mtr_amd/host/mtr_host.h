@@ -67,6 +67,8 @@ typedef struct mtrh_engine {
     __typeof__(mtr_gather_last_error) *gather_last_error;
     __typeof__(mtr_gather_stage) *gather_stage;
     __typeof__(mtr_gather_exchange) *gather_exchange;
+    __typeof__(mtr_gather_wait_ready) *gather_wait_ready;
+    __typeof__(mtr_gather_get_stats) *gather_get_stats;
     char path[4096];                    /* the library that was bound, resolved (reported by mTR -c) */
 } mtrh_engine;
 /* dlopen a library that implements include/mtr_hip.h; lib_path NULL = $MTR_LIB, else libmtr_hip.so next to this code */
@@ -167,19 +169,21 @@ uint8_t *mtrh_run_round_blob(mtrh_run *r, int round, size_t *bytes);
  * N runs, one per GPU (its own parser threads, device thread and contexts; chunk c of the plan belongs to GPU c % N, or longest-first
  * over the GPUs for several files), merged in output order by the calling thread.  The path's one exchange: per round the staged
  * wire-form tables of every GPU are gathered to the first GPU over RCCL (mtr_gather_exchange) and chained + printed from there.
- * Without RCCL (a device given twice: more ranks than GPUs; librccl missing; MTR_GATHER=host; -a, whose chains are made where the
- * batch is resident) every GPU's tables are fetched to the host directly - same output. */
+ * RCCL comes up in the background (2 s on an MI355X box: more than a 100 000-read job takes) and is used from the round that finds it up; until
+ * then - and where it cannot be used at all - the staged tables are copied straight to the host by the same call.  No gather object at all (every
+ * GPU's device thread fetches its tables itself): MTR_GATHER=host, -a (the chains are made where the batch is resident), one GPU (nothing to
+ * gather), more ranks than GPUs (a rehearsal on a shared card).  MTR_GATHER=rccl waits for RCCL before the first batch.  Same output always. */
 typedef struct mtrh_multi mtrh_multi;
 typedef struct mtrh_printer mtrh_printer;
 mtrh_multi *mtrh_multi_start(const mtrh_opts *o, int n_gpus, const char *const *paths, int n_paths);
 /* every result to the printer in output order (blocks until the runs are through); 0, or -1 after an exchange failed */
 int   mtrh_multi_drain(mtrh_multi *m, mtrh_printer *p);
-/* "rccl" or "host", the number of exchanges, bytes gathered; sums of the runs' timers as mtrh_run_timing / mtrh_run_phase_times give them */
-const char *mtrh_multi_gather_mode(const mtrh_multi *m, long long *exchanges, long long *bytes);
-const char *mtrh_multi_gather_note(const mtrh_multi *m);       /* why the gather is "host" when RCCL was asked for ("" otherwise) */
+/* one line for mTR -c: how the tables reached the printer ("<N> GPUs\tgather rccl, ..." / "... gather host, ...") */
+void  mtrh_multi_gather_line(const mtrh_multi *m, char *buf, size_t n);
 mtrh_run *mtrh_multi_run(const mtrh_multi *m, int gpu);
 int   mtrh_multi_n(const mtrh_multi *m);
-void  mtrh_multi_stop(mtrh_multi *m);
+/* returns 1 when RCCL was still coming up in the background (a job shorter than the library's start-up): the caller leaves through _exit */
+int   mtrh_multi_stop(mtrh_multi *m);
 
 /* ---- printing: chaining.cpp:125-171 (+ the alignment block of wrap_around_DP.c:187-212 with -a) --------------------- */
 typedef struct mtrh_printer mtrh_printer;

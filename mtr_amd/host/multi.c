@@ -9,9 +9,12 @@
  * thread hands the round's results to the printer in output order, where they are chained and printed as on one GPU (chain.c, print.c).  While
  * round t is gathered and printed the GPUs run round t + 1.
  *
- * Without RCCL the tables are fetched to the host by every GPU's own device thread (mtr_fetch_results_packed): MTR_GATHER=host, -a (the chains are
- * made where the batch is resident, which needs the records on the host there), more ranks than GPUs (RCCL takes a device once; a rehearsal of
- * N runs on one card), or librccl missing.  The output is the same byte for byte.
+ * RCCL comes up in the background (loading librccl.so + ncclCommInitAll: 2.2 s measured on an MI355X box, three times the whole 100 000-read job):
+ * a round that finds it up goes over RCCL, an earlier one copies the staged tables straight to the host inside the same call (mtr_hip.h), and a job
+ * that ends before RCCL is up leaves without waiting for it.  No gather at all - every GPU's device thread fetches its own tables
+ * (mtr_fetch_results_packed) - with MTR_GATHER=host, -a (the chains are made where the batch is resident, which needs the records on the host there),
+ * one GPU (nothing to gather) and more ranks than GPUs (a rehearsal of N runs on one card).  MTR_GATHER=rccl waits for RCCL before the first batch and
+ * fails if it cannot be had.  The output is the same byte for byte in every case.
  */
 #define _GNU_SOURCE
 #include "mtr_host.h"
@@ -20,17 +23,21 @@
 
 struct mtrh_multi {
     int n; mtrh_run **runs; mtrh_engine eng; mtr_gather *gather;
-    char mode[8]; char note[300];
-    long long exchanges, bytes;
+    char note[300];
+    long long bytes;
 };
 
-const char *mtrh_multi_gather_mode(const mtrh_multi *m, long long *exchanges, long long *bytes)
+void mtrh_multi_gather_line(const mtrh_multi *m, char *buf, size_t n)
 {
-    if (exchanges) *exchanges = m->exchanges;
-    if (bytes) *bytes = m->bytes;
-    return m->mode;
+    if (!m->gather) { snprintf(buf, n, "%d GPUs\tgather host, 0 exchange(s), %lld bytes of record tables%s%s%s", m->n, m->bytes, m->note[0] ? " (" : "", m->note, m->note[0] ? ")" : ""); return; }
+    int64_t st[6] = { 0, 0, 0, 0, 0, 0 };
+    (void)m->eng.gather_get_stats(m->gather, st, 6);
+    char up[96] = "";
+    if (st[5] == 1) snprintf(up, sizeof up, "RCCL up after %lld ms", (long long)st[4]);
+    else snprintf(up, sizeof up, st[5] == 0 ? "RCCL still coming up when the job ended" : "RCCL not usable");
+    snprintf(buf, n, "%d GPUs\tgather rccl, %lld exchange(s) over RCCL + %lld straight to the host, %lld bytes of record tables (%s%s%s)", m->n, (long long)st[0], (long long)st[1],
+             (long long)(st[2] + st[3]), up, m->note[0] ? "; " : "", m->note);
 }
-const char *mtrh_multi_gather_note(const mtrh_multi *m) { return m->note; }
 mtrh_run *mtrh_multi_run(const mtrh_multi *m, int gpu) { return gpu >= 0 && gpu < m->n ? m->runs[gpu] : NULL; }
 int mtrh_multi_n(const mtrh_multi *m) { return m->n; }
 
@@ -48,25 +55,24 @@ mtrh_multi *mtrh_multi_start(const mtrh_opts *o, int n_gpus, const char *const *
     m->n = n_gpus;
     int32_t *dev = (int32_t *)calloc((size_t)n_gpus, sizeof(int32_t));
     for (int r = 0; r < n_gpus; r++) dev[r] = (o->device + r) % ndev;             /* -d k: the first GPU; more ranks than GPUs share (a rehearsal) */
-    /* the gather: RCCL unless something rules it out */
+    /* the gather: RCCL (in the background) unless something rules it out */
     const char *want = getenv("MTR_GATHER");
-    snprintf(m->mode, sizeof m->mode, "host");
+    const int want_rccl = want && strcmp(want, "rccl") == 0;
     if (want && strcmp(want, "host") == 0) snprintf(m->note, sizeof m->note, "MTR_GATHER=host");
     else if (o->print_alignment) snprintf(m->note, sizeof m->note, "-a: the chains are made where the batch is resident, the records go to the host there");
     else if (n_gpus > ndev) snprintf(m->note, sizeof m->note, "%d ranks on %d GPU(s): RCCL takes a device once per communicator", n_gpus, (int)ndev);
+    else if (n_gpus == 1 && !want_rccl) snprintf(m->note, sizeof m->note, "one GPU: nothing to gather");
     else {
-        const mtr_status st = m->eng.gather_create(n_gpus, dev, &m->gather);
-        if (st == MTR_OK) snprintf(m->mode, sizeof m->mode, "rccl");
-        else {
+        mtr_status st = m->eng.gather_create(n_gpus, dev, &m->gather);
+        if (st == MTR_OK && want_rccl) st = m->eng.gather_wait_ready(m->gather);          /* asked for by name: every round on RCCL, or not at all */
+        if (st != MTR_OK) {
             snprintf(m->note, sizeof m->note, "%s", m->gather ? m->eng.gather_last_error(m->gather) : "the gather could not be created");
             if (m->gather) m->eng.gather_destroy(m->gather);
             m->gather = NULL;
-            if (want && strcmp(want, "rccl") == 0) {                              /* asked for by name: do not fall back silently */
-                fprintf(stderr, "fatal error: MTR_GATHER=rccl, but %s\n", m->note);
-                free(dev); free(m); return NULL;
-            }
+            if (want_rccl) { fprintf(stderr, "fatal error: MTR_GATHER=rccl, but %s\n", m->note); free(dev); free(m); return NULL; }
         }
     }
+    if (want_rccl && !m->gather) { fprintf(stderr, "fatal error: MTR_GATHER=rccl, but %s\n", m->note); free(dev); free(m); return NULL; }
     m->runs = (mtrh_run **)calloc((size_t)n_gpus, sizeof(mtrh_run *));
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
     for (int r = 0; r < n_gpus; r++) {
@@ -128,7 +134,6 @@ int mtrh_multi_drain(mtrh_multi *m, mtrh_printer *p)
                     x->ticket = -1;
                     m->bytes += sizes[j];
                 }
-                m->exchanges++;
             }
         }
         for (int i = 0; i < n; i++) {
@@ -142,11 +147,17 @@ int mtrh_multi_drain(mtrh_multi *m, mtrh_printer *p)
     return failed ? -1 : 0;
 }
 
-void mtrh_multi_stop(mtrh_multi *m)
+int mtrh_multi_stop(mtrh_multi *m)
 {
-    if (!m) return;
+    if (!m) return 0;
+    int pending = 0;
     for (int r = 0; r < m->n; r++) mtrh_run_stop(m->runs[r]);
-    if (m->gather) m->eng.gather_destroy(m->gather);
+    if (m->gather) {
+        int64_t st[6] = { 0, 0, 0, 0, 0, 0 };
+        if (m->eng.gather_get_stats(m->gather, st, 6) == MTR_OK && st[5] == 0) pending = 1;      /* RCCL still coming up: nobody waits for it */
+        m->eng.gather_destroy(m->gather);
+    }
     free(m->runs);
     free(m);
+    return pending;
 }

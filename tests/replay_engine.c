@@ -203,19 +203,28 @@ mtr_status mtr_alignments(mtr_ctx *c, int32_t n, const int32_t *read_idx, const 
 #include <pthread.h>
 #define RG_SLOTS 1024
 typedef struct { uint8_t *p; int64_t bytes; int busy; } rg_slot;
-struct mtr_gather { int n; rg_slot *slots; pthread_mutex_t mu; uint8_t *host; size_t host_cap; char err[128]; long long exchanges; };
+struct mtr_gather { int n; rg_slot *slots; pthread_mutex_t mu; uint8_t *host; size_t host_cap; char err[128]; long long exchanges, bytes; int usable; };
 
 mtr_status mtr_device_count(int32_t *out) { if (!out) return MTR_ERR_BAD_ARG; const char *e = getenv("MTR_REPLAY_DEVICES"); *out = e ? atoi(e) : 8; return *out > 0 ? MTR_OK : MTR_ERR_NO_DEVICE; }
 const char *mtr_gather_last_error(const mtr_gather *g) { return g ? g->err : "no gather"; }
 mtr_status mtr_gather_create(int32_t n, const int32_t *devices, mtr_gather **out)
-{
+{   /* like the product: the object always comes into being; whether "RCCL" is usable shows in mtr_gather_wait_ready / mtr_gather_get_stats */
     if (!out || n <= 0 || !devices) return MTR_ERR_BAD_ARG;
     mtr_gather *g = (mtr_gather *)calloc(1, sizeof *g);
     *out = g;
-    if (getenv("MTR_REPLAY_GATHER_FAIL")) { snprintf(g->err, sizeof g->err, "replayed failure: no RCCL here"); return MTR_ERR_NO_DEVICE; }
-    for (int r = 0; r < n; r++) for (int q = 0; q < r; q++) if (devices[q] == devices[r]) { snprintf(g->err, sizeof g->err, "device %d is given to two ranks", devices[r]); return MTR_ERR_NO_DEVICE; }
+    g->usable = 1;
+    if (getenv("MTR_REPLAY_GATHER_FAIL")) { snprintf(g->err, sizeof g->err, "replayed failure: no RCCL here"); g->usable = 0; }
+    for (int r = 0; r < n; r++) for (int q = 0; q < r; q++) if (devices[q] == devices[r]) { snprintf(g->err, sizeof g->err, "device %d is given to two ranks", devices[r]); g->usable = 0; }
     g->n = n; g->slots = (rg_slot *)calloc((size_t)n * RG_SLOTS, sizeof(rg_slot));
     pthread_mutex_init(&g->mu, NULL);
+    return MTR_OK;
+}
+mtr_status mtr_gather_wait_ready(mtr_gather *g) { return !g ? MTR_ERR_BAD_ARG : g->usable ? MTR_OK : MTR_ERR_NO_DEVICE; }
+mtr_status mtr_gather_get_stats(const mtr_gather *g, int64_t *out, int32_t n)
+{
+    if (!g || !out) return MTR_ERR_BAD_ARG;
+    const int64_t v[6] = { g->usable ? g->exchanges : 0, g->usable ? 0 : g->exchanges, g->usable ? g->bytes : 0, g->usable ? 0 : g->bytes, g->usable ? 1 : 0, g->usable ? 1 : -1 };
+    for (int i = 0; i < n && i < 6; i++) out[i] = v[i];
     return MTR_OK;
 }
 void mtr_gather_destroy(mtr_gather *g)
@@ -259,6 +268,7 @@ mtr_status mtr_gather_exchange(mtr_gather *g, int32_t n, const int32_t *tickets,
         out_ptrs[i] = g->host + off; out_bytes[i] = s->bytes;
         off += ((size_t)s->bytes + 255) & ~(size_t)255;
         s->busy = 0;
+        g->bytes += s->bytes;
     }
     g->exchanges++;
     pthread_mutex_unlock(&g->mu);

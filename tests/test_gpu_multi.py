@@ -96,8 +96,8 @@ def test_gather_api_moves_the_wire_form_through_rccl(eng):
     for b in batches:
         eng.process(b)
         want.append(eng.fetch_packed())
-    for self_send in ("1", "0"):
-        os.environ["MTR_GATHER_SELF"] = self_send
+    for self_send in ("1", "0", "early"):
+        os.environ["MTR_GATHER_SELF"] = "1" if self_send == "early" else self_send
         try:
             g = C.c_void_p()
             dev = (C.c_int32 * 1)(0)
@@ -105,6 +105,9 @@ def test_gather_api_moves_the_wire_form_through_rccl(eng):
             assert st == 0, lib.mtr_gather_last_error(g)
         finally:
             del os.environ["MTR_GATHER_SELF"]
+        # RCCL comes up in the background; "early" does not wait: its first exchange most likely finds RCCL not up and copies straight to the host
+        if self_send != "early":
+            assert lib.mtr_gather_wait_ready(g) == 0, lib.mtr_gather_last_error(g)
         e2 = mtr_amd.Engine()
         for rounds in range(2):                                    # the second round reuses the staging slots and the buffers
             tickets = []
@@ -126,11 +129,25 @@ def test_gather_api_moves_the_wire_form_through_rccl(eng):
                 assert sizes[i] == len(data) and C.string_at(ptrs[i], sizes[i]) == data, (self_send, rounds, i)
             assert lib.mtr_gather_exchange(g, len(tickets), tk, ptrs, sizes) != 0          # the tickets were released
         e2.close()
+        st6 = (C.c_int64 * 6)()
+        assert lib.mtr_gather_wait_ready(g) == 0
+        assert lib.mtr_gather_get_stats(g, st6, 6) == 0 and st6[0] + st6[1] == 2 and st6[5] == 1 and st6[4] > 0
+        if self_send == "1":
+            assert st6[0] == 2 and st6[2] == 2 * sum(len(d) for d, _ in want)        # both exchanges over RCCL (to the GPU itself)
+        if self_send == "0":
+            assert st6[0] == 0 and st6[3] == 2 * sum(len(d) for d, _ in want)        # the first GPU's own tables take the local copy
         lib.mtr_gather_destroy(g)
-    # a device given twice is refused with a reason (the host then fetches every GPU's tables directly)
+    # a device given twice: RCCL cannot be had (the reason is kept), the exchange still delivers - straight to the host
     g = C.c_void_p()
     dev = (C.c_int32 * 2)(0, 0)
-    assert lib.mtr_gather_create(2, dev, C.byref(g)) != 0 and b"two ranks" in lib.mtr_gather_last_error(g)
+    assert lib.mtr_gather_create(2, dev, C.byref(g)) == 0
+    assert lib.mtr_gather_wait_ready(g) != 0 and b"two ranks" in lib.mtr_gather_last_error(g)
+    eng.upload(batches[0]); eng.run()
+    cnt = (C.c_int32 * len(batches[0]))()
+    total, nbytes, ticket = C.c_int64(), C.c_int64(), C.c_int32()
+    assert lib.mtr_gather_stage(g, 1, eng.h, cnt, C.byref(total), C.byref(nbytes), C.byref(ticket)) == 0
+    ptrs, sizes, tk = (C.c_void_p * 1)(), (C.c_int64 * 1)(), (C.c_int32 * 1)(ticket.value)
+    assert lib.mtr_gather_exchange(g, 1, tk, ptrs, sizes) == 0 and C.string_at(ptrs[0], sizes[0]) == want[0][0]
     lib.mtr_gather_destroy(g)
 
 
@@ -149,7 +166,7 @@ def test_c_host_over_gpus_config4_and_config5():
         line = _gather_line(p)
         assert line.startswith(f"{g} GPUs\tgather {mode}, "), line
         if mode == "rccl":
-            assert " 0 exchange" not in line
+            assert ", 0 exchange(s) over RCCL" not in line and "+ 0 straight to the host" in line, line
         p = _mtr_g(["-p", "-c", "-g", str(g), *files], extra)
         assert p.returncode == 0, p.stderr.decode()[-800:]
         assert p.stdout == b"".join(golden(nm, "p") for nm in BUNDLED), (g, mode)
@@ -197,7 +214,7 @@ def test_c_host_rccl_config4_ten_thousand_reads_against_the_oracles_hash(tmp_pat
     assert p.returncode == 0, p.stderr.decode()[-800:]
     assert p.stdout == one.stdout
     line = _gather_line(p)
-    assert "gather rccl" in line and int(line.split(" exchange")[0].split()[-1]) >= 4 // n, line
+    assert "gather rccl" in line and int(line.split(" exchange")[0].split()[-1]) >= 4 // n and "+ 0 straight to the host" in line, line
 
 
 def _run(args, world, backend=None):

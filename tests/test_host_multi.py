@@ -49,7 +49,10 @@ def test_config4_in_small_over_n_gpus(cli, tables, gpus, chunk):
     assert p.returncode == 0, p.stderr.decode()[-500:]
     assert p.stdout == _golden("synth_c4")
     line = _gather_line(p)
-    assert line.startswith(f"{gpus} GPUs\tgather rccl, ") and " 0 exchange" not in line, line
+    if gpus == 1:
+        assert line.startswith("1 GPUs\tgather host, ") and "nothing to gather" in line, line
+    else:
+        assert line.startswith(f"{gpus} GPUs\tgather rccl, ") and ", 0 exchange(s) over RCCL" not in line and "+ 0 straight to the host" in line, line
 
 
 def test_config5_files_longest_first_with_pearson(cli, tables):
@@ -61,7 +64,7 @@ def test_config5_files_longest_first_with_pearson(cli, tables):
         p = _run(cli, tables, ["-p", "-c", "-g", str(gpus), *[gu.input_path(n) for n in names]], mode="p")
         assert p.returncode == 0, p.stderr.decode()[-500:]
         assert p.stdout == want, gpus
-        assert "gather rccl, 1 exchange(s)" in _gather_line(p)
+        assert "gather rccl, 1 exchange(s) over RCCL" in _gather_line(p)
 
 
 def test_alignments_and_the_host_gather(cli, tables):
@@ -70,10 +73,18 @@ def test_alignments_and_the_host_gather(cli, tables):
     p = _run(cli, tables, ["-a", "-c", "-g", "2", gu.input_path("synth_c2")], MTR_CHUNK_BYTES=5000)
     assert p.returncode == 0 and p.stdout == _golden("synth_c2", "a")
     assert "gather host, 0 exchange(s)" in _gather_line(p)
-    for extra in ({"MTR_GATHER": "host"}, {"MTR_REPLAY_GATHER_FAIL": "1"}, {"MTR_REPLAY_DEVICES": "1"}):
+    for extra in ({"MTR_GATHER": "host"}, {"MTR_REPLAY_DEVICES": "1"}):
         p = _run(cli, tables, ["-c", "-g", "3", gu.input_path("synth_c4")], MTR_CHUNK_BYTES=3000, **extra)
         assert p.returncode == 0 and p.stdout == _golden("synth_c4"), extra
         assert "gather host, 0 exchange(s)" in _gather_line(p), extra
+    # RCCL that never comes up (missing library, ...): the staged tables go straight to the host inside the exchange, round by round
+    p = _run(cli, tables, ["-c", "-g", "3", gu.input_path("synth_c4")], MTR_CHUNK_BYTES=3000, MTR_REPLAY_GATHER_FAIL=1)
+    assert p.returncode == 0 and p.stdout == _golden("synth_c4")
+    line = _gather_line(p)
+    assert "gather rccl, 0 exchange(s) over RCCL + " in line and "+ 0 straight" not in line and "RCCL not usable" in line, line
+    # one GPU with RCCL asked for by name (the rehearsal of the RCCL path on a one-GPU box)
+    p = _run(cli, tables, ["-c", "-g", "1", gu.input_path("synth_c4")], MTR_CHUNK_BYTES=3000, MTR_GATHER="rccl")
+    assert p.returncode == 0 and p.stdout == _golden("synth_c4") and "gather rccl, " in _gather_line(p)
     # RCCL asked for by name where it cannot be had: an error, not a silent fall-back
     p = _run(cli, tables, ["-g", "3", gu.input_path("synth_c4")], MTR_GATHER="rccl", MTR_REPLAY_GATHER_FAIL="1")
     assert p.returncode != 0 and b"MTR_GATHER=rccl" in p.stderr and p.stdout == b""

@@ -241,7 +241,13 @@ def main():
     # MTR_BENCH_FORCE_DIST=1 (under torch.distributed.run with ONE rank): the N > 1 code path - process group, size exchange,
     # gather to rank 0 - on a single GPU, to exercise the RCCL calls where only one GPU is available
     dist_on = world > 1 or os.environ.get("MTR_BENCH_FORCE_DIST") == "1"
+    report = sys.stdout
     if dist_on:
+        # stdout carries ONE JSON line: RCCL prints its version banner on descriptor 1 at the first collective, so the line keeps a descriptor of its own and
+        # descriptor 1 points at stderr from here on
+        sys.stdout.flush()
+        report = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -691,7 +697,8 @@ def main():
             out["value_launcher"] = lr.get("reads_per_s")
         dist.barrier()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), file=report)
+        report.flush()
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

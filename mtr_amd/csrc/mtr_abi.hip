@@ -898,7 +898,10 @@ static mtr_status launch_staged(mtr_ctx *ctx)
             hipLaunchKernelGGL(mtr_k_rscatter, dim3((unsigned)capped(512, 16384)), dim3(256), 0, ctx->stream, s, ctx->d_status);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(ctx->ev_dom[0][pass][0], ctx->stream));
-            hipLaunchKernelGGL(mtr_k_revise_quads, dim3((unsigned)capped(waves, 256)), dim3(64), 0, ctx->stream, a, s);
+            // eight slots per wavefront: MTR_REV_WAVES_PER_CU (development) bounds the grid - fewer wavefronts = more revisions in a row per slot
+            static const int rev_wpc = getenv("MTR_REV_WAVES_PER_CU") ? atoi(getenv("MTR_REV_WAVES_PER_CU")) : 0;
+            const int waves_rev = rev_wpc > 0 ? std::min(waves, ctx->n_cu * rev_wpc) : waves;
+            hipLaunchKernelGGL(mtr_k_revise_quads, dim3((unsigned)capped(waves_rev, 256)), dim3(64), 0, ctx->stream, a, s);
             HIPCHK(hipEventRecord(ctx->ev_dom[0][pass][1], ctx->stream));
         } else hipLaunchKernelGGL(mtr_k_revise, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
         HIPCHK(hipGetLastError());

@@ -218,6 +218,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="the default line without its secondary.c3 object (BASELINE config 3 measured in a child process)")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-cli", action="store_true")
+    ap.add_argument("--no-upload-leg", action="store_true", help="skip value_with_upload (profiling passes: only launches of the resident headline batch)")
     a = ap.parse_args()
 
     import torch
@@ -434,7 +435,7 @@ def main():
     dt_upload = None
     if world == 1:
         dt_kernel, _ = timed(a.steps, fetch=False)      # round 1's figure: the kernels alone, results left on the device
-        if not a.strong and a.config is None:
+        if not a.strong and a.config is None and not a.no_upload_leg:
             # the boundary handing over HOST buffers: every step takes a FRESH batch (three different read sets in turn) as concatenated base
             # codes + offsets + lengths in host memory (mtr_upload_batch: 2-bit packing on the calling thread + the copy to the device), runs
             # it and fetches its tables; the upload of step s+1 overlaps the kernels of step s (two contexts), as in the host pipeline

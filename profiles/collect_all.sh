@@ -18,7 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 # bench.py asks for 8 hardware queues (an RCCL communicator's streams must not push the two context streams onto one queue);
 # under rocprofv3 that setting serialises the two contexts' launches (92 ms a step), the runtime's default of 4 does not (56 ms)
 export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-4}
-BENCH="python3 $ROOT/bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-latency --no-cli --no-secondary"
+BENCH="python3 $ROOT/bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-latency --no-cli --no-secondary --no-upload-leg"
 run() { name=$1; shift; timeout -k 10 300 rocprofv3 "$@" -d "$OUT/$name" -o $name --output-format csv -- $BENCH > "$OUT/bench_$name.json" 2> "$OUT/$name.err" || { tail -5 "$OUT/$name.err"; exit 1; }; echo "$name done"; }
 run trace --kernel-trace --stats
 run fetch --pmc FETCH_SIZE

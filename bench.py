@@ -654,7 +654,7 @@ def main():
             out["launcher_rccl_forced"] = launcher_rate(reads, 10 * len(reads), 1, force_rccl=True)
             try:        # the command line's own part: from the first device context (the runtime is up) to the end of the run
                 st = c10["stamps_s"]
-                own = st["run stopped"] - st["first device context created"]
+                own = st.get("run stopped", st["everything printed"]) - st["first device context created"]
                 out["cli"]["ten_batches_after_runtime_start"] = {"seconds": own, "reads_per_s": c10["reads"] / own}
             except Exception:
                 pass

@@ -692,7 +692,7 @@ def main():
             torch.cuda.empty_cache()
             t0 = time.perf_counter()
             try:
-                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "c3", "--steps", "4", "--warmup", "1", "--cpu-sample", str(min(a.cpu_sample, 6))]
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "c3", "--steps", "12", "--warmup", "2", "--cpu-sample", str(min(a.cpu_sample, 6))]
                                    + (["--no-cli"] if a.no_cli else []), capture_output=True, text=True, cwd=ROOT, timeout=420)
                 try:
                     sec = json.loads(p.stdout.strip().splitlines()[-1])

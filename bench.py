@@ -661,6 +661,10 @@ def main():
                 e.close()
             engs.clear()
             torch.cuda.empty_cache()
+            # this process has just given ~50 GB of device memory back: the driver reclaims it in the background, and a child that allocates meanwhile waits
+            # for it (measured: the second context's first launch of a run 0.64 s instead of 0.01 s, all three runs of the leg).  A pause and one untimed run first.
+            time.sleep(2.0)
+            cli_rate(reads, 2000)
             c1 = cli_rate(reads, len(reads))
             c10 = cli_rate(reads, 10 * len(reads))
             out["value_cli"] = c10.get("reads_per_s")

@@ -578,8 +578,9 @@ def main():
             "kernels_mode_timed": eng.last_mode(),
             "work_per_launch": {k: cnt[k] for k in ("dp_calls", "dp_cells", "dp_rows", "revise_dp_calls", "revise_dp_cells", "memo_hits", "memo_cells",
                                                     "kmer_tables", "tables_skipped", "kmer_lookups", "ranges_executed", "ranges_searched", "records", "traceback_steps", "revisions_shared", "reads_sent_back")},
-            "quad_passes": {"note": "four-per-wavefront DP passes (dp_quad.hip.inc): bytes of cell matrix written (every row of all four 16-lane groups up to the pass's longest member) "
-                                    "per cell of the DPs the pass was run for; alignments: one byte holds the cell of both parameter sets",
+            "quad_passes": {"note": "the DP passes that carry several DPs per wavefront (dp_quad.hip.inc: four two-parameter alignments, eight one-parameter revision DPs): bytes of cell "
+                                    "matrix written (every row of every DP of the pass up to the pass's longest member) per cell of the DPs the pass was run for; alignments: one byte "
+                                    "holds the cell of both parameter sets; revisions: a byte holds two rows",
                             "alignments_bytes_per_cell_pair": (cnt["qpass_bytes_dp2"] / cnt["qpass_cells_dp2"]) if cnt["qpass_cells_dp2"] else None,
                             "revisions_bytes_per_cell": (cnt["qpass_bytes_rev"] / cnt["qpass_cells_rev"]) if cnt["qpass_cells_rev"] else None,
                             "alignments_bytes": cnt["qpass_bytes_dp2"], "revisions_bytes": cnt["qpass_bytes_rev"]},

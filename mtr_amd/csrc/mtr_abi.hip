@@ -785,6 +785,10 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     s.work = (unsigned *)(sc + 64 * 32);
     // wide windows first (k3_staged.hip.inc): the chain in two passes.  MTR_TWO_PASS=0 / 1 overrides
     s.two_pass = staged_two_pass(sumL, n); s.pass = 0; s.defer_w = 160;
+    // the alignment passes in a scattered order (k3_staged.hip.inc: st_scatter_stride): alone the kernel is 2 % slower (12.1 against 11.9 ms), two contexts'
+    // launches overlapped are 0.6 ms a step faster (36.6 against 37.2 ms, two runs each) - what runs next to the other context's kernels is a steady mixture of
+    // shapes instead of one shape at a time.  MTR_PASS_SHUFFLE=0: list order (development)
+    { static const int shuffle = getenv("MTR_PASS_SHUFFLE") ? atoi(getenv("MTR_PASS_SHUFFLE")) : 1; s.pass_shuffle = shuffle; }
     if (s.two_pass) {
         ST_ALLOC(ensure_dev(ctx, ctx->d_st_ipass, (size_t)std::max(s.item_cap, 1))); ST_ALLOC(ensure_dev(ctx, ctx->d_st_plist0, (size_t)std::max(s.item_cap, 1) * 4));
         ST_ALLOC(ensure_dev(ctx, ctx->d_st_plist1, (size_t)std::max(s.item_cap, 1) * 4)); ST_ALLOC(ensure_dev(ctx, ctx->d_st_re2, (size_t)std::max<int64_t>(ctx->total_rcap, 1) * 4));

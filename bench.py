@@ -525,9 +525,9 @@ def main():
                                                                 else "HIP events around the kernel's launches in the timed region (no warm-up launch ran)"),
                         "duration_ms_in_timed_region": dom_timed_ms,
                         "cells_per_launch": dom_cells, "ops_per_cell": OPS_PER_CELL,
-                        "cells_note": "cells (rows x unit) of the vote DPs and re-alignments the kernel ran in its four-per-wavefront passes"}
+                        "cells_note": "cells (rows x unit) of the vote DPs and re-alignments the kernel ran in its passes of up to eight DPs per wavefront"}
         else:       # a batch whose chain runs one DP per wavefront (small batches) or the per-read kernel: no kernel of its own to name - the launch
-            roofline = {"bound": "valu-issue", "kernel": "one launch (the chain ran one DP per wavefront: no dominant four-per-wavefront kernel)",
+            roofline = {"bound": "valu-issue", "kernel": "one launch (the chain ran one DP per wavefront: no dominant several-DPs-per-wavefront kernel)",
                         "achieved": valu_ops / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s", "frac": valu_ops / VALU_PEAK_LANE_OPS,
                         "duration_ms": k2_avg_s * 1e3, "cells_per_launch": cells, "ops_per_cell": OPS_PER_CELL}
         roofline.update({

@@ -9,8 +9,9 @@ the per-read kernels (candidate ranges, unit search, wrap-around DPs, revision; 
 the boundary's lower edge — the record tables compacted on the device to the wire form and copied into pinned host
 memory (mtr_fetch_results_packed), i.e. the arguments of insert_an_alignment_into_set where the host's chaining takes
 them.  Workload = the configuration BASELINE.json's metric is quoted on: 10 000 synthetic Nanopore-error reads of ~2 kb
-(unit 100 x 10 copies, 500-base flanks; mtr_amd.synth "headline2k") per GPU.  Steps alternate between two contexts, so
-the fetch of step s overlaps the kernels of step s+1, as in the host pipeline (mtr_amd/host/pipeline.c).
+(unit 100 x 10 copies, 500-base flanks; mtr_amd.synth "headline2k") per GPU.  Steps take turns on three contexts (three
+batches in flight, as the host pipeline keeps them on a long job: mtr_amd/host/pipeline.c), so the fetch of step s
+overlaps the kernels of the steps behind it.
 
   value          reads/s at the boundary (above);            value_kernel  the same steps without the fetch (round 1's figure)
   value_cli      reads/s of the command line mtr_amd/host/mTR on a FASTA of the same reads, wall clock incl. process
@@ -208,8 +209,8 @@ def launcher_rate(reads, n_total, n_gpus, force_rccl=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)            # (1.5 s of timed steps: the timed region starts on an idle GPU, and filling three batches in flight is
+    ap.add_argument("--warmup", type=int, default=4)           #  one launch's worth of time that a short run spreads over few steps)
     ap.add_argument("--reads", type=int, default=READS_PER_GPU, help="reads per GPU (default = the headline workload)")
     ap.add_argument("--strong", default=None, choices=["c4"], help="strong scaling: one fixed read set split over the ranks")
     ap.add_argument("--strong-reads", type=int, default=100000)
@@ -293,15 +294,16 @@ def main():
         # every rank owns its own block of reads (weak scaling): same distribution, different seed
         reads = [c for _, c in synth.make_reads(WORKLOAD, a.reads, seed=2 + rank)]
         n_job = len(reads) * world
-    # Two contexts (own stream, own result and scratch buffers) hold the same resident batch: consecutive steps alternate
-    # between them, so the kernels of step s+1 are enqueued while step s is fetched (and while its last wavefronts finish:
+    # The contexts (own stream, own result and scratch buffers; three: round 5 measured 36.64 / 36.13 / 36.02 ms a step with two / three / four) hold the same
+    # resident batch: consecutive steps take turns on them, so the kernels of step s+1 are enqueued while step s is fetched (and while its last wavefronts finish:
     # a read is one wavefront's serial chain).  Every step does all of its work.  With an exchange step (N > 1) one more
     # context, so that the next kernel is already enqueued while the host waits for the gather of the previous step.
     # --strong: ONE data set is the whole job, so a step is the whole job - kernels, then the gather, then the copy to the host, one after the other on
     # one context (repetitions of a job do not overlap each other; round 4 pipelined them and measured the next repetition's persistent kernels holding
     # the wavefront slots the gather's kernels were waiting for: 687 ms a step for a 335 ms launch).  Config 3: three batches in flight, as the host
     # pipeline runs long reads (launches bound by their longest work items leave most of the chip idle: 78.5 ms a step with two, 53.8 with three).
-    NCTX = int(os.environ.get("MTR_BENCH_CONTEXTS", "1" if a.strong else "3" if (dist_on or a.config == "c3") else "2"))
+    # batches in flight: three (the host pipeline's choice for long jobs and for long reads: mtr_amd/host/pipeline.c); a strong step is the whole job: one
+    NCTX = int(os.environ.get("MTR_BENCH_CONTEXTS", "1" if a.strong else "3"))
     engs = [mtr_amd.Engine(device=local_rank) for _ in range(NCTX)]
     for e in engs:
         e.upload(reads)                                 # inputs resident in HBM before the timed region
@@ -697,7 +699,7 @@ def main():
             torch.cuda.empty_cache()
             t0 = time.perf_counter()
             try:
-                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "c3", "--steps", "12", "--warmup", "2", "--cpu-sample", str(min(a.cpu_sample, 6))]
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "c3", "--steps", "24", "--warmup", "3", "--cpu-sample", str(min(a.cpu_sample, 6))]
                                    + (["--no-cli"] if a.no_cli else []), capture_output=True, text=True, cwd=ROOT, timeout=420)
                 try:
                     sec = json.loads(p.stdout.strip().splitlines()[-1])

@@ -403,6 +403,13 @@ static void device_body(mtrh_run *r, device_state *d)
                 int64_t bases = 0;
                 for (int i = 0; i < b->n; i++) bases += b->lens[i];
                 nctx = bases / (b->n > 0 ? b->n : 1) >= 8000 ? 3 : 2;
+                /* a long job of short reads: a third batch in flight is worth 1.4 % ([measured] 10 000 reads of 2 kb per batch: 36.64 / 36.13 / 36.02 ms a step
+                 * with two / three / four) and costs a third context's memory (16 GB) and creation (~40 ms): from ~32 batches on */
+                if (nctx == 2 && bases > 0) {
+                    int64_t mine = 0;
+                    for (int c = 0; c < r->n_chunks; c++) if (r->chunks[c].owner == r->o.rank) mine += (int64_t)(r->chunks[c].end - r->chunks[c].begin);
+                    if (mine / bases >= 32) nctx = 3;
+                }
             }
             mtr_ctx **pc = &ctxs[k % nctx];
             mtr_status st = MTR_OK;

@@ -127,6 +127,8 @@ struct K2Layout {
     size_t pol_u, pol_rev;         // int32 [512] each (polish work arrays)
     size_t gkeys, gvals;           // int32 [gcap]: counts of the k-mer table (always) and keys of windows that do not fit LDS
     size_t ckeys, cslots;          // int32 [gcap / 2] each: the keys of such a table once more, compact, and their slots (the look-ahead scans these)
+    size_t gkf, gsf, gkb, gsb;     // int32 [gcap / 2] each: the same keys and slots grouped by their first five digits (f) / last five (b), made when a
+                                   //   table's first general look-ahead step in that direction needs them (k2_units.hip.inc: idx_build)
     size_t ties;                   // int32 [2][1024] tie lists of the look-ahead
     size_t memo_unit, memo_res;    // DP memo of the current range: uint8 [K2_MEMO_N][512] units, int32 [K2_MEMO_N][16] results
     size_t step_cache;             // int32 [2][K2_STEP_CACHE][4]: node, next node, number of the table the entry is for, 0 - the walks' general look-ahead steps, per direction
@@ -173,6 +175,10 @@ static inline __host__ __device__ K2Layout k2_layout(int Lmax, long long cells_c
     y.gvals = o; o = mtrc_align(o + (size_t)g * 4, 16);
     y.ckeys = o; o = mtrc_align(o + (size_t)(g / 2) * 4, 16);
     y.cslots = o; o = mtrc_align(o + (size_t)(g / 2) * 4, 16);
+    y.gkf = o; o = mtrc_align(o + (size_t)(g / 2) * 4, 16);
+    y.gsf = o; o = mtrc_align(o + (size_t)(g / 2) * 4, 16);
+    y.gkb = o; o = mtrc_align(o + (size_t)(g / 2) * 4, 16);
+    y.gsb = o; o = mtrc_align(o + (size_t)(g / 2) * 4, 16);
     y.total = mtrc_align(o, 256);
     return y;
 }

@@ -113,6 +113,7 @@ typedef struct {
     mtrh_batch *head, *cur;
     int64_t cap_reads, cap_codes, cap_words, n_codes;
     int max_reads; int64_t max_bases;
+    int64_t hint_codes;                    /* bytes of the chunk still to parse when the batch was opened: its bases cannot be more */
 } builder;
 
 static mtrh_batch *batch_new(void)
@@ -134,7 +135,8 @@ static uint8_t *codes_room(builder *B, int64_t have, int64_t more)
 {
     mtrh_batch *b = B->cur;
     if (B->n_codes + have + more > B->cap_codes) {
-        int64_t c = B->cap_codes ? B->cap_codes * 2 : (1 << 20);
+        /* the first allocation takes what the chunk can hold at most (doubling from 1 MB copied a 24 MB chunk's codes five times over: 31 MB of memcpy) */
+        int64_t c = B->cap_codes ? B->cap_codes * 2 : (B->hint_codes > (1 << 20) ? B->hint_codes + MTRH_BLK : (1 << 20));
         while (c < B->n_codes + have + more) c *= 2;
         b->codes = (uint8_t *)xrealloc(b->codes, (size_t)c); B->cap_codes = c;
     }
@@ -153,7 +155,7 @@ static void read_done(builder *B, int64_t len, const char *id, int32_t id_len)
     }
     const int64_t nw = mtr_packed_words((int32_t)len);
     if (b->n_words + nw > B->cap_words) {
-        int64_t c = B->cap_words ? B->cap_words * 2 : (1 << 18);
+        int64_t c = B->cap_words ? B->cap_words * 2 : (B->hint_codes / 12 > (1 << 18) ? B->hint_codes / 12 : (1 << 18));      /* (bases / 16 + 4 words per read: a twelfth of the bytes covers reads of 200 bases and more) */
         while (c < b->n_words + nw) c *= 2;
         b->packed = (uint32_t *)xrealloc(b->packed, sizeof(uint32_t) * (size_t)c); B->cap_words = c;
     }
@@ -161,7 +163,7 @@ static void read_done(builder *B, int64_t len, const char *id, int32_t id_len)
     b->lens[i] = (int32_t)len; b->offs[i] = B->n_codes; b->woff[i] = b->n_words; b->ids[i] = id; b->id_lens[i] = id_len;
     (void)mtr_pack_read(b->codes + B->n_codes, (int32_t)len, b->packed + b->n_words);    /* codes are 0..3 by construction */
     b->n_words += nw; B->n_codes += len;
-    if (b->n >= B->max_reads || B->n_codes >= B->max_bases) builder_open(B);
+    if (b->n >= B->max_reads || B->n_codes >= B->max_bases) { B->hint_codes = B->hint_codes > B->n_codes ? B->hint_codes - B->n_codes : 0; builder_open(B); }
 }
 
 mtrh_batch *mtrh_parse_chunk(const mtrh_file *f, size_t begin, size_t end, int max_reads, int64_t max_bases)
@@ -169,6 +171,7 @@ mtrh_batch *mtrh_parse_chunk(const mtrh_file *f, size_t begin, size_t end, int m
     init_codes();
     builder B; memset(&B, 0, sizeof B);
     B.max_reads = max_reads > 0 ? max_reads : 16384; B.max_bases = max_bases > 0 ? max_bases : ((int64_t)512 << 20);
+    B.hint_codes = (int64_t)(end - begin) < B.max_bases ? (int64_t)(end - begin) : B.max_bases;
     builder_open(&B);
     const unsigned char *p = (const unsigned char *)f->map + begin, *e = (const unsigned char *)f->map + end;
     const char *id = NULL; int32_t id_len = 0;        /* ID of the record being read ("" until a header was seen) */

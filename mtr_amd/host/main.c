@@ -4,6 +4,7 @@
 #define _POSIX_C_SOURCE 200809L
 #include "mtr_host.h"
 #include <stdlib.h>
+#include <malloc.h>
 #include <string.h>
 #include <unistd.h>
 #include <sys/time.h>
@@ -53,8 +54,11 @@ int main(int argc, char **argv)
     { const char *cb = getenv("MTR_CHUNK_BYTES"); if (cb && atoll(cb) > 0) o.chunk_bytes = (size_t)atoll(cb); }     /* FASTA bytes per chunk (default 24 MiB = one device batch of 2 kb reads) */
     if (optind >= argc) { fprintf(stderr, "The input file name is expected argument after options\n"); exit(EXIT_FAILURE); }
 
+    /* Batches, record tables and text buffers are tens of MB each and come and go at the rate of the GPUs: as mappings of their own (glibc's default
+     * above 128 KB .. 32 MB, adjusted as it goes) every one of them is an mmap, a page fault per 4 KB and a munmap whose TLB shoot-down stops every thread
+     * of the process - a quarter of the host's CPU time behind eight GPUs (tests/null_engine.c: sys 2.2 s of 6.9 s per million reads).  Kept in the heaps. */
+    mallopt(M_MMAP_THRESHOLD, 32 << 20); mallopt(M_TRIM_THRESHOLD, 1 << 30);
     const double t_all = now();
-    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
     mtrh_run *run = NULL; mtrh_multi *multi = NULL;
     int status = 0; double t_chain = 0;
     if (n_gpus >= 1) {
@@ -66,7 +70,7 @@ int main(int argc, char **argv)
         if (report_fd < 0 || dup2(2, 1) < 0) { fprintf(stderr, "fatal error: cannot set the report's descriptor aside\n"); exit(EXIT_FAILURE); }
         multi = mtrh_multi_start(&o, n_gpus, (const char *const *)(argv + optind), argc - optind);
         if (!multi) exit(EXIT_FAILURE);
-        mtrh_printer *pr = mtrh_printer_start_fd(report_fd, ncpu >= 8 ? 4 : (ncpu >= 4 ? 2 : 1));
+        mtrh_printer *pr = mtrh_printer_start_fd(report_fd, mtrh_printer_default_threads());
         const int drained = mtrh_multi_drain(multi, pr);
         status = mtrh_printer_finish(pr, &t_chain);
         if (drained != 0) status = 1;
@@ -74,7 +78,7 @@ int main(int argc, char **argv)
         const char *paths[1] = { argv[optind] };
         run = mtrh_run_start(&o, paths, 1);
         if (!run) exit(EXIT_FAILURE);
-        mtrh_printer *pr = mtrh_printer_start(stdout, ncpu >= 8 ? 4 : (ncpu >= 4 ? 2 : 1));
+        mtrh_printer *pr = mtrh_printer_start(stdout, mtrh_printer_default_threads());
         for (mtrh_result *x; (x = mtrh_run_next(run)) != NULL; ) mtrh_printer_push(pr, x);
         status = mtrh_printer_finish(pr, &t_chain);
     }
@@ -124,7 +128,8 @@ int main(int argc, char **argv)
         if (gather_line[0]) fprintf(stderr, "%s\n", gather_line);                 /* this build, -g N: how the tables reached the printer */
     }
     if (leave_fast) {                             /* the fast way out (above); with MTR_FULL_TEARDOWN still taken when RCCL is coming up on its thread: no teardown under it */
-        fflush(stdout); fflush(stderr);
+        if (fflush(stdout) != 0) status = 1;        /* (the report itself: the printer flushed it and its status says whether that worked, mtrh_printer_finish) */
+        fflush(stderr);
         _exit(status ? EXIT_FAILURE : EXIT_SUCCESS);
     }
     return status ? EXIT_FAILURE : EXIT_SUCCESS;

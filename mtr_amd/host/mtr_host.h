@@ -121,6 +121,7 @@ typedef struct mtrh_result {
     int32_t  n_report;                     /* reads to report: batch->n, fewer after a device-side failure */
     int32_t *counts;  uint8_t *wire; int64_t wire_bytes;     /* records per read, wire form */
     int32_t  ticket;                       /* >= 0: the wire form is still on the GPU, staged for the gather (mtr_gather_stage); wire is filled by the exchange */
+    int32_t  fetched_by_run;               /* a gather exists, but this table came to the host with the run's own fetch (every staging slot of its GPU was taken) */
     /* -a only: the chains (made where the batch was resident) and the alignment paths of their records */
     int32_t  with_alignments;
     int32_t *chain_len; int32_t *chain_idx; int64_t n_chain;  /* per read: length; concatenated record indices (within the read) */
@@ -197,6 +198,10 @@ void  mtrh_printer_push(mtrh_printer *p, mtrh_result *r);
 int   mtrh_printer_finish(mtrh_printer *p, double *t_chain);
 /* rank 0: the blobs of every rank for one round -> results in output order -> the printer; -1 = a malformed blob */
 int   mtrh_print_round(mtrh_printer *p, const uint8_t *const *blobs, const size_t *sizes, int n_blobs);
+/* pool threads for a printer by the cores of the machine (half of them, 2 .. 16) */
+int   mtrh_printer_default_threads(void);
+/* "%f" of (float)matches / repeat_len without printf (print.c); out holds 64 bytes; returns the length */
+int   mtrh_format_ratio(int matches, int repeat_len, char *out);
 /* formats one result into a malloc'ed buffer (used by the printer's pool; exposed for tests) */
 char *mtrh_format_result(const mtrh_result *r, int first_read, int last_read, size_t *out_len);
 #endif

@@ -52,6 +52,14 @@ mtrh_multi *mtrh_multi_start(const mtrh_opts *o, int n_gpus, const char *const *
         fprintf(stderr, "fatal error: no usable HIP device; this build has no CPU path\n");
         free(m); return NULL;
     }
+    /* The files are looked at BEFORE the gather exists: mtr_gather_create starts a thread that loads librccl.so and runs ncclCommInitAll (~2 s), and a caller
+     * that leaves through exit() after a plain user error (`mTR -g 2 typo.fa`) would tear the runtime down under that thread.  A file that cannot
+     * be opened is reported here, with the reader's own message (fasta.c, handle_one_file.c:192-196), while nothing runs yet. */
+    for (int f = 0; f < n_paths; f++) {
+        mtrh_file probe;
+        if (mtrh_file_open(&probe, paths[f]) != 0) { free(m); return NULL; }
+        mtrh_file_close(&probe);
+    }
     m->n = n_gpus;
     int32_t *dev = (int32_t *)calloc((size_t)n_gpus, sizeof(int32_t));
     for (int r = 0; r < n_gpus; r++) dev[r] = (o->device + r) % ndev;             /* -d k: the first GPU; more ranks than GPUs share (a rehearsal) */
@@ -83,7 +91,8 @@ mtrh_multi *mtrh_multi_start(const mtrh_opts *o, int n_gpus, const char *const *
         m->runs[r] = mtrh_run_start(&q, paths, n_paths);
         if (!m->runs[r]) {
             for (int t = 0; t < r; t++) mtrh_run_stop(m->runs[t]);
-            if (m->gather) m->eng.gather_destroy(m->gather);
+            /* (a run that cannot start although its files opened a moment ago: the caller will exit(), so RCCL's start-up thread is waited for first) */
+            if (m->gather) { (void)m->eng.gather_wait_ready(m->gather); m->eng.gather_destroy(m->gather); }
             free(m->runs); free(dev); free(m);
             return NULL;
         }
@@ -138,7 +147,7 @@ int mtrh_multi_drain(mtrh_multi *m, mtrh_printer *p)
         }
         for (int i = 0; i < n; i++) {
             if (failed && res[i]->ticket >= 0) { mtrh_result_free(res[i]); continue; }      /* its table never arrived */
-            if (!m->gather) m->bytes += res[i]->wire_bytes;
+            if (!m->gather || res[i]->fetched_by_run) m->bytes += res[i]->wire_bytes;
             mtrh_printer_push(p, res[i]);
         }
         if (failed) break;

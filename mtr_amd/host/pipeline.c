@@ -246,9 +246,13 @@ static void finish_batch(mtrh_run *r, mtr_ctx *ctx, mtrh_result *x)
         /* several GPUs: the table stays on this GPU, compacted to the wire form, until the round's exchange takes it to the first GPU (multi.c) */
         int64_t bytes = 0, total = 0; int32_t ticket = -1;
         st = r->eng.gather_stage(r->o.gather, r->o.rank, ctx, x->counts, &total, &bytes, &ticket);
-        if (st != MTR_OK) { result_fail(x, 0, r->eng.last_error(ctx)); n_report = 0; }
-        else { x->ticket = ticket; x->wire_bytes = bytes; }
-    } else if (n_report > 0) {
+        if (st == MTR_OK) { x->ticket = ticket; x->wire_bytes = bytes; }
+        else if (st != MTR_ERR_OVERFLOW) { result_fail(x, 0, r->eng.last_error(ctx)); n_report = 0; }
+    }
+    /* no gather - or every staging slot of this GPU holds a table that waits for its round's exchange (several files: ONE round, so a GPU with more than
+     * the pool's batches staged them all): the table comes to the host with this thread's own fetch, as on one GPU */
+    if (n_report > 0 && x->ticket < 0 && !(x->fatal && n_report == 0)) {
+        if (r->o.gather && !x->fatal && !r->o.print_alignment) x->fetched_by_run = 1;
         const uint8_t *blob = NULL; const int32_t *counts = NULL; int64_t bytes = 0, total = 0;
         st = r->eng.fetch_packed(ctx, x->fatal ? n_report : -1, &blob, &bytes, &counts, &total);
         if (st != MTR_OK) { result_fail(x, 0, r->eng.last_error(ctx)); n_report = 0; }
@@ -406,9 +410,9 @@ static void device_body(mtrh_run *r, device_state *d)
                 /* a long job of short reads: a third batch in flight is worth 1.4 % ([measured] 10 000 reads of 2 kb per batch: 36.64 / 36.13 / 36.02 ms a step
                  * with two / three / four) and costs a third context's memory (16 GB) and creation (~40 ms): from ~32 batches on */
                 if (nctx == 2 && bases > 0) {
-                    int64_t mine = 0;
-                    for (int c = 0; c < r->n_chunks; c++) if (r->chunks[c].owner == r->o.rank) mine += (int64_t)(r->chunks[c].end - r->chunks[c].begin);
-                    if (mine / bases >= 32) nctx = 3;
+                    int64_t my_bytes = 0;                    /* FASTA bytes of this rank's chunks: about its bases (headers and line ends are a per cent) */
+                    for (int q = 0; q < r->n_chunks; q++) if (r->chunks[q].owner == r->o.rank) my_bytes += (int64_t)(r->chunks[q].end - r->chunks[q].begin);
+                    if (my_bytes / bases >= 32) nctx = 3;
                 }
             }
             mtr_ctx **pc = &ctxs[k % nctx];
@@ -418,6 +422,15 @@ static void device_body(mtrh_run *r, device_state *d)
                 st = r->eng.create(r->o.device, r->o.manhattan, r->o.min_match_ratio, pc);
                 pthread_mutex_lock(&r->mu); r->t_create += now_s() - tc; pthread_mutex_unlock(&r->mu);
                 mtrh_stamp(k == 0 ? "first device context created" : k == 1 ? "second device context created" : "third device context created");
+                if (st != MTR_OK && k % nctx >= 1) {
+                    /* a second or third context that cannot be had (a card shared with other ranks, a smaller one): the job goes on with the contexts it has -
+                     * every batch in flight is finished first, so that the context the next batch takes is idle */
+                    *pc = NULL;
+                    finish_all(r, d);
+                    nctx = k % nctx; k = 0;
+                    pc = &ctxs[0]; st = MTR_OK;
+                    mtrh_stamp("a further device context could not be created: going on with fewer batches in flight");
+                }
                 if (st != MTR_OK) {
                     char m[256];
                     snprintf(m, sizeof m, "fatal error: no usable HIP device (mtr_create returned %d); this build has no CPU path", (int)st);

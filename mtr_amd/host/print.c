@@ -10,6 +10,8 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 
 enum { T_MATCH = 1, T_MISMATCH = 2, T_DEL = 3, T_INS = 4 };
 static const char BASE[4] = { 'A', 'C', 'G', 'T' };
@@ -51,25 +53,72 @@ static void tb_int(tbuf *b, int v)
     while (k) b->s[b->n++] = t[--k];
 }
 
+/* printf("%f", (float)matches / repeat_len) (chaining.cpp:136-137: the float quotient, promoted to double) without printf: a float is M x 2^e with a 24-bit M,
+ * so M x 10^6 is an exact 44-bit integer and the six decimals are its quotient by 2^-e, rounded half to even on the exact remainder - what glibc's
+ * correctly rounded conversion prints.  snprintf was a third of the formatting time of a report line.  Anything unusual (negative, >= 2^24, inf, nan:
+ * a zero repeat_len) goes to snprintf.  out must hold 64 bytes; returns the number of characters.  tests/test_host_ceiling.py compares the two. */
+int mtrh_format_ratio(int matches, int repeat_len, char *out)
+{
+    const float f = (float)matches / repeat_len;
+    uint32_t bits; memcpy(&bits, &f, 4);
+    const int ex = (int)((bits >> 23) & 0xffu);
+    if ((bits >> 31) || ex == 255 || ex >= 150 + 24) return snprintf(out, 64, "%f", f);
+    uint64_t q;                                        /* the value x 10^6, rounded */
+    if (ex == 0) q = 0;                                /* zero and subnormals: below 10^-37 */
+    else {
+        const uint64_t N = (uint64_t)((bits & 0x7fffffu) | 0x800000u) * 1000000ull;
+        const int e = ex - 150;                        /* value = M x 2^e */
+        if (e >= 0) q = N << e;                        /* (M < 2^24, e < 24: an integer below 2^48, times 10^6 below 2^64 only for e <= 20 - larger: snprintf) */
+        else if (-e > 62) q = 0;
+        else {
+            const int s = -e;
+            const uint64_t rem = N & ((1ull << s) - 1ull), half = 1ull << (s - 1);
+            q = N >> s;
+            if (rem > half || (rem == half && (q & 1ull))) q++;
+        }
+        if (e > 20) return snprintf(out, 64, "%f", f);
+    }
+    uint64_t ip = q / 1000000ull; unsigned fr = (unsigned)(q % 1000000ull);
+    char t[24]; int k = 0, n = 0;
+    do { t[k++] = (char)('0' + ip % 10); ip /= 10; } while (ip);
+    while (k) out[n++] = t[--k];
+    out[n++] = '.';
+    for (int d = 5; d >= 0; d--) { out[n + d] = (char)('0' + fr % 10); fr /= 10; }
+    n += 6;
+    out[n] = 0;
+    return n;
+}
+
 /* chaining.cpp:127-143: ID L start+1 end+1 repeat_len period copies matches ratio mismatches insertions deletions unit */
+static inline char *put_int(char *o, int v)
+{   /* "%d" */
+    char t[16]; int k = 0; unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+    do { t[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) *o++ = '-';
+    while (k) *o++ = t[--k];
+    return o;
+}
 static void report_line(tbuf *b, const char *id, int id_len, int L, const mtrh_rec *r)
 {
-    tb_put(b, id, (size_t)id_len); tb_ch(b, '\t');
-    tb_int(b, L); tb_ch(b, '\t');
-    tb_int(b, r->h[MTRH_REP_START] + 1); tb_ch(b, '\t');
-    tb_int(b, r->h[MTRH_REP_END] + 1); tb_ch(b, '\t');
-    tb_int(b, r->h[MTRH_REPEAT_LEN]); tb_ch(b, '\t');
-    tb_int(b, r->h[MTRH_PERIOD]); tb_ch(b, '\t');
-    tb_int(b, r->h[MTRH_COPIES]); tb_ch(b, '\t');
-    tb_int(b, r->h[MTRH_MATCHES]); tb_ch(b, '\t');
-    tb_room(b, 64);
-    b->n += (size_t)snprintf(b->s + b->n, 64, "%f", (float)r->h[MTRH_MATCHES] / r->h[MTRH_REPEAT_LEN]);    /* a float division, printed as a double */
-    tb_ch(b, '\t');
-    tb_int(b, r->h[MTRH_MISMATCHES]); tb_ch(b, '\t');
-    tb_int(b, r->h[MTRH_INSERTIONS]); tb_ch(b, '\t');
-    tb_int(b, r->h[MTRH_DELETIONS]); tb_ch(b, '\t');
     int per = r->h[MTRH_PERIOD]; if (per < 0) per = 0;
-    tb_put(b, r->unit, strnlen(r->unit, (size_t)per)); tb_ch(b, '\n');
+    tb_room(b, (size_t)id_len + (size_t)per + 256);       /* ONE check per line: ten integers of at most 11 characters, the ratio (at most 64), twelve tabs */
+    char *o = b->s + b->n;
+    memcpy(o, id, (size_t)id_len); o += id_len; *o++ = '\t';
+    o = put_int(o, L); *o++ = '\t';
+    o = put_int(o, r->h[MTRH_REP_START] + 1); *o++ = '\t';
+    o = put_int(o, r->h[MTRH_REP_END] + 1); *o++ = '\t';
+    o = put_int(o, r->h[MTRH_REPEAT_LEN]); *o++ = '\t';
+    o = put_int(o, r->h[MTRH_PERIOD]); *o++ = '\t';
+    o = put_int(o, r->h[MTRH_COPIES]); *o++ = '\t';
+    o = put_int(o, r->h[MTRH_MATCHES]); *o++ = '\t';
+    o += mtrh_format_ratio(r->h[MTRH_MATCHES], r->h[MTRH_REPEAT_LEN], o);             /* a float division, printed as a double */
+    *o++ = '\t';
+    o = put_int(o, r->h[MTRH_MISMATCHES]); *o++ = '\t';
+    o = put_int(o, r->h[MTRH_INSERTIONS]); *o++ = '\t';
+    o = put_int(o, r->h[MTRH_DELETIONS]); *o++ = '\t';
+    const size_t ul = strnlen(r->unit, (size_t)per);
+    memcpy(o, r->unit, ul); o += ul; *o++ = '\n';
+    b->n = (size_t)(o - b->s);
 }
 
 /* the block after a report line with -a: ops[] = one byte per column, last column first; end_pos = read position of the
@@ -176,40 +225,96 @@ char *mtrh_format_result(const mtrh_result *r, int first_read, int last_read, si
     return b.s;
 }
 
-/* ---- the printer: one manager thread takes results in order; a pool formats slices of a result; the manager writes ---- */
+/* ---- the printer: results in output order through three stages - prepared and formatted by a pool, written by one thread ----
+ * Round 6: up to `depth` results are in the printer at once.  A result is a job: one pool thread walks its wire form for the reads' starts
+ * (read_starts: a serial walk over the records' headers), then the pool formats its slices - of THIS job and of the jobs behind it, whatever
+ * is claimable -, and the writer thread emits finished jobs in order.  Before (one manager thread: format a result's slices, wait, write,
+ * next result) the pool idled while the manager wrote and the writer idled while the pool formatted: 1.1-1.2 s per million reads whatever
+ * the number of cores, the ceiling of `mTR -g 8` behind eight GPUs (measured with tests/null_engine.c).  What ends a file's output
+ * (a device-side error, a fatal character, an empty record, a failed allocation) is decided by the writer, in order, as before. */
 #define MAX_PRINT_THREADS 32
-typedef struct qnode { mtrh_result *r; struct qnode *next; } qnode;
+#define MAX_SLICES (MAX_PRINT_THREADS * 4)
+typedef struct pjob {
+    mtrh_result *r; fmt_ctx f; int64_t *cf;
+    int prep_claimed, prepared, malformed, oom;
+    int n_slices, next_slice, done_slices; int slice_first[MAX_SLICES + 1]; tbuf slice_buf[MAX_SLICES];
+    struct pjob *next;
+} pjob;
 struct mtrh_printer {
-    FILE *out; int threads;
-    pthread_t manager, pool[MAX_PRINT_THREADS];
+    FILE *out; int threads, depth;
+    pthread_t writer, pool[MAX_PRINT_THREADS];
     pthread_mutex_t mu; pthread_cond_t cv_q, cv_job, cv_done;
-    qnode *head, *tail; int closing; int queued;
-    /* the result being formatted */
-    fmt_ctx job; int n_slices, next_slice, done_slices; int slice_first[MAX_PRINT_THREADS * 4 + 1]; tbuf slice_buf[MAX_PRINT_THREADS * 4];
-    int pool_exit;
-    int oom;                                           /* a thread of the pool could not allocate while it formatted a slice */
+    pjob *head, *tail; int closing, queued, pool_exit;
     int status, ended, cur_file; double t_chain;
 };
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
+/* the reads' starts in the wire form and the slices of the job (any thread, outside the lock) */
+static void job_prepare(pjob *j, int threads)
+{
+    mtrh_result *r = j->r; const int n = r->n_report;
+    j->f.r = r; j->f.chain_first = NULL;
+    j->f.starts = read_starts(r);
+    if (!j->f.starts) { j->malformed = 1; j->n_slices = 0; return; }
+    if (r->with_alignments) {
+        j->cf = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n + 1));
+        j->cf[0] = 0;
+        for (int i = 0; i < n; i++) j->cf[i + 1] = j->cf[i] + r->chain_len[i];
+        j->f.chain_first = j->cf;
+    }
+    const int slices = threads > 1 && n >= 256 ? threads * 4 : 1;
+    for (int s = 0; s <= slices; s++) j->slice_first[s] = (int)((int64_t)n * s / slices);
+    j->n_slices = slices;
+}
+
+static void job_free(pjob *j)
+{
+    for (int s = 0; s < MAX_SLICES; s++) free(j->slice_buf[s].s);
+    free((void *)j->f.starts); free(j->cf);
+    mtrh_result_free(j->r);
+    free(j);
+}
+
+/* a unit of work of the pool: the preparation of a job, or one slice of a prepared job - the oldest job first (the lock is held) */
+static __attribute__((noinline)) pjob *claim_unit(mtrh_printer *p, int *unit)
+{
+    for (pjob *q = p->head; q; q = q->next) {
+        if (!q->prep_claimed) { q->prep_claimed = 1; *unit = -1; return q; }
+        if (q->prepared && q->next_slice < q->n_slices) { *unit = q->next_slice++; return q; }
+    }
+    return NULL;
+}
 static void *pool_main(void *arg)
 {
     mtrh_printer *p = (mtrh_printer *)arg;
     mtrh_thread_kind = MTRH_THREAD_PRINTER;
     pthread_mutex_lock(&p->mu);
     for (;;) {
-        while (!p->pool_exit && p->next_slice >= p->n_slices) pthread_cond_wait(&p->cv_job, &p->mu);
-        if (p->pool_exit) break;
-        const int s = p->next_slice++;
+        int unit = -2;                                 /* -1: prepare, >= 0: slice */
+        pjob *const j = claim_unit(p, &unit);
+        if (unit == -2) {
+            if (p->pool_exit) break;
+            pthread_cond_wait(&p->cv_job, &p->mu);
+            continue;
+        }
         pthread_mutex_unlock(&p->mu);
-        jmp_buf oom;                                   /* (alloc.c: a failed allocation inside format_reads comes back here) */
+        jmp_buf oom;                                   /* (alloc.c: a failed allocation inside the unit comes back here) */
         const int failed = setjmp(oom);
-        if (!failed) { mtrh_oom_target = &oom; format_reads(&p->job, p->slice_first[s], p->slice_first[s + 1], &p->slice_buf[s]); }
+        if (!failed) {
+            mtrh_oom_target = &oom;
+            if (unit < 0) job_prepare(j, p->threads);
+            else format_reads(&j->f, j->slice_first[unit], j->slice_first[unit + 1], &j->slice_buf[unit]);
+        }
         mtrh_oom_target = NULL;
         pthread_mutex_lock(&p->mu);
-        if (failed) p->oom = 1;
-        if (++p->done_slices == p->n_slices) pthread_cond_broadcast(&p->cv_done);
+        if (failed) j->oom = 1;                        /* (a failure belongs to the result whose unit it hit, not to every later one) */
+        if (unit < 0) {
+            if (failed) j->n_slices = 0;
+            j->prepared = 1;
+            pthread_cond_broadcast(&p->cv_job);        /* its slices can be claimed */
+            if (j->n_slices == 0) pthread_cond_broadcast(&p->cv_done);
+        } else if (++j->done_slices == j->n_slices) pthread_cond_broadcast(&p->cv_done);
     }
     pthread_mutex_unlock(&p->mu);
     return NULL;
@@ -224,41 +329,14 @@ static void end_message(const mtrh_batch *bt)
                 MTR_MAX_INPUT_LENGTH, MTR_MAX_INPUT_LENGTH, (int)bt->end_id_len, bt->end_id ? bt->end_id : "");
 }
 
-static void print_one(mtrh_printer *p, mtrh_result *r)
+/* the writer's part of a finished job: its text, then whatever ends the file's output */
+static void write_job(mtrh_printer *p, pjob *j)
 {
-    const double t0 = now_s();
+    mtrh_result *r = j->r;
     const mtrh_batch *bt = r->batch;
-    const int n = r->n_report;
-    fmt_ctx f; f.r = r; f.starts = read_starts(r); f.chain_first = NULL;
-    int64_t *cf = NULL;
-    if (!f.starts) { fprintf(stderr, "internal error: malformed record table\n"); p->status = 1; p->ended = 1; return; }
-    if (r->with_alignments) {
-        cf = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n + 1));
-        cf[0] = 0;
-        for (int i = 0; i < n; i++) cf[i + 1] = cf[i] + r->chain_len[i];
-        f.chain_first = cf;
-    }
-    int slices = p->threads > 1 && n >= 256 ? p->threads * 4 : 1;
-    if (slices == 1) {
-        tbuf b = { NULL, 0, 0 };
-        format_reads(&f, 0, n, &b);
-        if (b.n) fwrite(b.s, 1, b.n, p->out);
-        free(b.s);
-    } else {
-        pthread_mutex_lock(&p->mu);
-        p->job = f; p->done_slices = 0; p->oom = 0;            /* (a failure belongs to the result whose slices it hit, not to every later one) */
-        for (int s = 0; s <= slices; s++) p->slice_first[s] = (int)((int64_t)n * s / slices);
-        for (int s = 0; s < slices; s++) p->slice_buf[s].n = 0;
-        p->n_slices = slices; p->next_slice = 0;
-        pthread_cond_broadcast(&p->cv_job);
-        while (p->done_slices < slices) pthread_cond_wait(&p->cv_done, &p->mu);
-        const int pool_failed = p->oom;
-        pthread_mutex_unlock(&p->mu);
-        if (pool_failed) { free((void *)f.starts); free(cf); mtrh_oom(0); }       /* (reported by manager_main like its own failure) */
-        for (int s = 0; s < slices; s++) if (p->slice_buf[s].n) fwrite(p->slice_buf[s].s, 1, p->slice_buf[s].n, p->out);
-    }
-    free((void *)f.starts); free(cf);
-    p->t_chain += now_s() - t0;
+    if (j->oom) { fflush(p->out); fprintf(stderr, "fatal error: cannot allocate memory\n"); p->status = 1; p->ended = 1; return; }
+    if (j->malformed) { fprintf(stderr, "internal error: malformed record table\n"); p->status = 1; p->ended = 1; return; }
+    for (int s = 0; s < j->n_slices; s++) if (j->slice_buf[s].n) fwrite(j->slice_buf[s].s, 1, j->slice_buf[s].n, p->out);
     if (r->fatal) {                                     /* a device-side error: like the reference, everything before it is out first */
         fflush(p->out);
         fprintf(stderr, "%s\n", r->fatal_msg ? r->fatal_msg : "device error");
@@ -271,28 +349,35 @@ static void print_one(mtrh_printer *p, mtrh_result *r)
     }
 }
 
-static void *manager_main(void *arg)
+static void *writer_main(void *arg)
 {
     mtrh_printer *p = (mtrh_printer *)arg;
     mtrh_thread_kind = MTRH_THREAD_PRINTER;
     for (;;) {
         pthread_mutex_lock(&p->mu);
-        while (!p->head && !p->closing) pthread_cond_wait(&p->cv_q, &p->mu);
-        qnode *q = p->head;
-        if (!q) { pthread_mutex_unlock(&p->mu); break; }
-        p->head = q->next; if (!p->head) p->tail = NULL;
+        while (!p->head && !p->closing) pthread_cond_wait(&p->cv_done, &p->mu);
+        pjob *j = p->head;
+        if (!j) { pthread_mutex_unlock(&p->mu); break; }
+        const double t0 = now_s();
+        if (p->threads <= 1) {                         /* no pool: this thread prepares and formats the job itself */
+            pthread_mutex_unlock(&p->mu);
+            jmp_buf oom;
+            if (setjmp(oom) == 0) {
+                mtrh_oom_target = &oom;
+                job_prepare(j, 1);
+                if (!j->malformed) format_reads(&j->f, 0, j->r->n_report, &j->slice_buf[0]);
+            } else { j->oom = 1; j->n_slices = 0; }
+            mtrh_oom_target = NULL;
+            pthread_mutex_lock(&p->mu);
+        } else while (!(j->prepared && j->done_slices == j->n_slices)) pthread_cond_wait(&p->cv_done, &p->mu);
+        p->head = j->next; if (!p->head) p->tail = NULL;
         p->queued--;
         pthread_cond_broadcast(&p->cv_q);
         pthread_mutex_unlock(&p->mu);
-        if (q->r->file_idx != p->cur_file) { p->cur_file = q->r->file_idx; p->ended = 0; }    /* every file is a run of its own */
-        if (!p->ended) {
-            jmp_buf oom;                               /* (alloc.c) the printer could not allocate: what is out stays out, the run ends with status 1 */
-            if (setjmp(oom) == 0) { mtrh_oom_target = &oom; print_one(p, q->r); }
-            else { fflush(p->out); fprintf(stderr, "fatal error: cannot allocate memory\n"); p->status = 1; p->ended = 1; }
-            mtrh_oom_target = NULL;
-        }
-        mtrh_result_free(q->r);
-        free(q);
+        if (j->r->file_idx != p->cur_file) { p->cur_file = j->r->file_idx; p->ended = 0; }    /* every file is a run of its own */
+        if (!p->ended) write_job(p, j);
+        p->t_chain += now_s() - t0;
+        job_free(j);
     }
     fflush(p->out);
     return NULL;
@@ -305,9 +390,10 @@ mtrh_printer *mtrh_printer_start(FILE *out, int threads)
     if (threads < 1) threads = 1;
     if (threads > MAX_PRINT_THREADS) threads = MAX_PRINT_THREADS;
     p->out = out; p->threads = threads; p->cur_file = -1;
+    p->depth = threads > 1 ? 4 + threads / 4 : 4;      /* results in the printer at once (bounded: they hold the reads' bases) */
     pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->cv_q, NULL); pthread_cond_init(&p->cv_job, NULL); pthread_cond_init(&p->cv_done, NULL);
     if (threads > 1) for (int t = 0; t < threads; t++) pthread_create(&p->pool[t], NULL, pool_main, p);
-    pthread_create(&p->manager, NULL, manager_main, p);
+    pthread_create(&p->writer, NULL, writer_main, p);
     return p;
 }
 
@@ -319,16 +405,25 @@ mtrh_printer *mtrh_printer_start_fd(int fd, int threads)
     FILE *f = fdopen(fd, "w");
     return f ? mtrh_printer_start(f, threads) : NULL;
 }
+/* threads for a printer by the cores of the machine: a quarter of them, 2 .. 16 (1 on a single core) */
+int mtrh_printer_default_threads(void)
+{
+    const long nc = sysconf(_SC_NPROCESSORS_ONLN);
+    if (nc < 2) return 1;
+    if (nc < 8) return 2;
+    return nc / 2 > 16 ? 16 : (int)(nc / 2);
+}
 
 void mtrh_printer_push(mtrh_printer *p, mtrh_result *r)
 {
-    qnode *q = (qnode *)calloc(1, sizeof *q);
-    q->r = r;
+    pjob *j = (pjob *)calloc(1, sizeof *j);
+    j->r = r;
     pthread_mutex_lock(&p->mu);
-    while (p->queued >= 4) pthread_cond_wait(&p->cv_q, &p->mu);        /* bounded: results hold the reads' bases */
-    if (p->tail) p->tail->next = q; else p->head = q;
-    p->tail = q; p->queued++;
-    pthread_cond_broadcast(&p->cv_q);
+    while (p->queued >= p->depth) pthread_cond_wait(&p->cv_q, &p->mu);
+    if (p->tail) p->tail->next = j; else p->head = j;
+    p->tail = j; p->queued++;
+    pthread_cond_broadcast(&p->cv_job);
+    pthread_cond_broadcast(&p->cv_done);
     pthread_mutex_unlock(&p->mu);
 }
 
@@ -336,16 +431,15 @@ int mtrh_printer_finish(mtrh_printer *p, double *t_chain)
 {
     pthread_mutex_lock(&p->mu);
     p->closing = 1;
-    pthread_cond_broadcast(&p->cv_q);
+    pthread_cond_broadcast(&p->cv_done);
     pthread_mutex_unlock(&p->mu);
-    pthread_join(p->manager, NULL);
+    pthread_join(p->writer, NULL);
     pthread_mutex_lock(&p->mu);
     p->pool_exit = 1;
     pthread_cond_broadcast(&p->cv_job);
     pthread_mutex_unlock(&p->mu);
     if (p->threads > 1) for (int t = 0; t < p->threads; t++) pthread_join(p->pool[t], NULL);
-    for (int s = 0; s < MAX_PRINT_THREADS * 4; s++) free(p->slice_buf[s].s);
-    const int st = p->status;
+    const int st = p->status | (ferror(p->out) ? 1 : 0);      /* a report that could not be written is a failed run */
     if (t_chain) *t_chain = p->t_chain;
     pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_q); pthread_cond_destroy(&p->cv_job); pthread_cond_destroy(&p->cv_done);
     free(p);

@@ -31,6 +31,52 @@ def build_replay():
     return REPLAY_LIB
 
 
+NULL_SRC = os.path.join(ROOT, "tests", "null_engine.c")
+NULL_LIB = os.path.join(ROOT, "tests", "libmtr_null.so")
+
+
+def build_null():
+    """tests/null_engine.c: an engine that costs the host nothing (every read answered with the same records at once) - the host pipeline's ceiling"""
+    hdr = os.path.join(ROOT, "include", "mtr_hip.h")
+    if not os.path.exists(NULL_LIB) or max(os.path.getmtime(NULL_SRC), os.path.getmtime(hdr)) > os.path.getmtime(NULL_LIB):
+        subprocess.run(["gcc", "-std=gnu11", "-O2", "-Wall", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
+                        "-o", NULL_LIB, NULL_SRC, "-lpthread"], check=True)
+    return NULL_LIB
+
+
+def host_ceiling(fasta, n_reads, n_gpus=8, records=2, repeats=2, extra_env=None):
+    """`mTR -g n_gpus <fasta>` behind the null engine: wall clock, CPU seconds (user + sys of the child) and lines printed; best of `repeats`.
+    The FASTA is the caller's (page cache warm after the first run)."""
+    import resource
+    import time
+    env = dict(os.environ, MTR_LIB=build_null(), MTR_NULL_RECORDS=str(records))
+    env.pop("MTR_REPLAY_TABLE", None)
+    if extra_env:
+        env.update(extra_env)
+    exe = build_host()
+    best = None
+    for _ in range(repeats):
+        r0 = resource.getrusage(resource.RUSAGE_CHILDREN)
+        t0 = time.perf_counter()
+        with open(os.devnull, "wb") as null:
+            p = subprocess.run([exe, "-g", str(n_gpus), fasta], stdout=subprocess.PIPE if best is None else null, stderr=subprocess.PIPE, env=env)
+        dt = time.perf_counter() - t0
+        r1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+        assert p.returncode == 0, p.stderr.decode()[-400:]
+        cur = {"seconds": dt, "user_s": r1.ru_utime - r0.ru_utime, "sys_s": r1.ru_stime - r0.ru_stime}
+        if best is None:
+            cur["lines"] = p.stdout.count(b"\n")
+            lines = cur["lines"]
+            best = cur                                   # (the first run also reads its report through a pipe: slower, kept only if nothing beats it)
+        elif dt < best["seconds"]:
+            cur["lines"] = lines
+            best = cur
+    best.update(reads=n_reads, gpus=n_gpus, records_per_read=records, reads_per_s=n_reads / best["seconds"],
+                cores_used=(best["user_s"] + best["sys_s"]) / best["seconds"], host_cores=os.cpu_count(),
+                reads_per_s_per_core_used=n_reads / (best["user_s"] + best["sys_s"]))
+    return best
+
+
 def hash_codes(codes: np.ndarray) -> int:
     """sum of (code + 1) * P^i mod 2^64 (tests/replay_engine.c: hash_codes)"""
     n = len(codes)

@@ -752,7 +752,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         s.sorted_cap = s.dp_cap + 4 * ST_QCLASSES;
     }
     ST_ALLOC(ensure_dev(ctx, ctx->d_st_arena, (size_t)s.arena_cap));
-    ST_ALLOC(ensure_dev(ctx, ctx->d_st_kc, (size_t)s.kc_cap * 8)); ST_ALLOC(ensure_dev(ctx, ctx->d_st_dp, (size_t)s.dp_cap * sizeof(StDpItem)));
+    ST_ALLOC(ensure_dev(ctx, ctx->d_st_kc, (size_t)s.kc_cap * 8 * 3));      /* (the block list; behind it the list of the blocks with a revision due and the one of mtr_k_select_slow) */ ST_ALLOC(ensure_dev(ctx, ctx->d_st_dp, (size_t)s.dp_cap * sizeof(StDpItem)));
     ST_ALLOC(ensure_dev(ctx, ctx->d_st_bincnt, (size_t)ST_NBINS * 4)); ST_ALLOC(ensure_dev(ctx, ctx->d_st_binstart, ((size_t)ST_NBINS + 1) * 4));
     ST_ALLOC(ensure_dev(ctx, ctx->d_st_dpbin, (size_t)s.dp_cap * 4)); ST_ALLOC(ensure_dev(ctx, ctx->d_st_dprank, (size_t)s.dp_cap * 4));
     ST_ALLOC(ensure_dev(ctx, ctx->d_st_sorted, (size_t)s.sorted_cap * 4)); ST_ALLOC(ensure_dev(ctx, ctx->d_st_classwave, 16 * 4));
@@ -776,7 +776,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     unsigned long long *sc = ctx->d_st_scalars;
     s.item_off = ctx->d_item_off; s.n_items = (int32_t *)(sc + 0 * 32);
     s.arena = ctx->d_st_arena; ctx->st_last_arena_cap = s.arena_cap; ctx->st_last_nsub = s.nsub;
-    s.kc_items = (long long *)ctx->d_st_kc;
+    s.kc_items = (long long *)ctx->d_st_kc; s.rb_items = s.kc_items + s.kc_cap; s.slow_items = s.rb_items + s.kc_cap;
     s.dp = ctx->d_st_dp;
     s.bin_count = ctx->d_st_bincnt; s.dp_bin = ctx->d_st_dpbin; s.dp_rank = ctx->d_st_dprank;
     s.bin_start = ctx->d_st_binstart; s.sorted = ctx->d_st_sorted; s.quad_cls = ctx->d_st_classwave;
@@ -879,6 +879,8 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         if (s.quad_min > 0) HIPCHK(hipMemsetAsync(ctx->d_st_bincnt, 0, (size_t)ST_NBINS * 4, ctx->stream));     // the revisions are sorted next
         HIPCHK(hipEventRecord(evp[4], ctx->stream));       // two-parameter alignments
         hipLaunchKernelGGL(mtr_k_select, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(mtr_k_select_slow, dim3((unsigned)std::min(waves, 64)), dim3(64), 0, ctx->stream, a, s);      // (blocks the kernel above left: normally none)
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(evp[5], ctx->stream));       // selection
         if (s.quad_min > 0) {

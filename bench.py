@@ -80,20 +80,41 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def profiled_counters():
-    """(traffic bytes/launch with the FETCH x 2 correction, VALU issue utilisation, tag) from profiles/pmc_latest.json, or
-    Nones when the kernel sources changed since that profile was taken."""
+def profiled_counters(config=None):
+    """The committed rocprofv3 PMC summary of THIS workload - profiles/pmc_latest.json for the headline, profiles/pmc_<config>.json for a secondary config
+    (profiles/collect_all.sh <tag> [--config c3]) - or None when there is none or the kernel sources changed since it was taken.  Round 5 read one file for every
+    config: the config-3 line carried the headline's traffic and issue figures."""
+    name = "pmc_latest.json" if config is None else f"pmc_{config}.json"
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
             p = json.load(fh)
     except Exception:
-        return None, None, "no profile"
+        return None, f"no profile of this workload (profiles/{name})"
     if p.get("kernel_src_sha") != kernel_sources_sha():
-        return None, None, f"stale: profiled at kernel sources {p.get('kernel_src_sha')}"
-    return p.get("k2_hbm_bytes_per_launch_fetch_x2"), p.get("valu_issue_utilisation"), p.get("tag", "")
+        return None, f"stale: profiles/{name} was taken at kernel sources {p.get('kernel_src_sha')}"
+    return p, p.get("tag", "")
 
 
-def cpu_baseline(reads, n_sample):
+def slot_time(prof):
+    """Wavefront-slot time of one launch of the chain from the profile's SQ_WAVE_CYCLES pass (x 4: the counter ticks once per four cycles): the sum over the chain's
+    kernels, what it is in ms on the chip's 4 096 slots of sixteen per CU, and every kernel's share.  The pipelined step is made of exactly this (round 5:
+    359.7 G = 36.6 ms against a 36.4 ms step), which is why a kernel that holds wavefronts without issuing anything costs the step its residence time."""
+    if not prof or "chain_per_launch" not in prof:
+        return None
+    ks = {k: v.get("wave_cycles", 0.0) for k, v in prof["chain_per_launch"].items()}
+    tot = sum(ks.values())
+    if tot <= 0:
+        return None
+    service = ("mtr_k_gather", "mtr_k_select", "mtr_k_select_slow", "mtr_k_rev_share", "mtr_k_finish", "mtr_k_polish", "mtr_k_replay", "mtr_k_pass_mark", "mtr_k_item_table")
+    return {"sum_wave_cycles": tot, "ms_on_4096_slots_at_2.4GHz": tot / (4096 * 2.4e9) * 1e3,
+            "service_kernels_wave_cycles": sum(v for k, v in ks.items() if k in service),
+            "service_kernels": list(service),
+            "kernels_G": {k: round(v / 1e9, 3) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]) if v >= 1e7},
+            "shares": {k: round(v / tot, 4) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]) if v / tot >= 0.002},
+            "source": "SQ_WAVE_CYCLES x 4 per kernel of the chain, rocprofv3 --pmc pass of the committed profile (pipelined launches)"}
+
+
+def cpu_baseline(reads, n_sample, p50_budget_s=20.0):
     """Time CPU mTR on the first n_sample reads (1 core).  Returns the cpu_baseline object."""
     from mtr_amd import synth
 
@@ -112,6 +133,23 @@ def cpu_baseline(reads, n_sample):
         dt = time.perf_counter() - t0
         one = {"value": len(sample) / dt, "unit": "reads/s", "cores": 1, "kind": kind,
                "sample": f"first {len(sample)} reads of the workload, one process, {dt:.1f} s"}
+        # ms/read p50 (BASELINE.json's metric is reads/sec + ms/read p50): the same binary, ONE READ PER PROCESS - the isolated semantics the parity contract is
+        # stated in, and the only way the reference's own per-read timers (handle_one_read.c:217-258, main.c:100-111) can be read per read -
+        # on the first reads of the sample, wall clock of each process
+        lat = []
+        n_lat = min(len(sample), 200 if p50_budget_s is None else 200)
+        t_budget = time.perf_counter()
+        for i in range(n_lat):
+            f1 = os.path.join(td, "one.fa")
+            synth.write_fasta(f1, [sample[i]])
+            t1 = time.perf_counter()
+            subprocess.run(cmd[:-1] + [f1], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            lat.append((time.perf_counter() - t1) * 1e3)
+            if p50_budget_s is not None and time.perf_counter() - t_budget > p50_budget_s:
+                break
+        if lat:
+            one["ms_per_read_p50"] = float(np.median(lat))
+            one["ms_per_read_p50_sample"] = f"{len(lat)} reads, one process per read (process start included: ~1 ms)"
         # the same binary on every host core of this box's share: one process per core, each on its own reads
         cores = max(1, min(16, len(os.sched_getaffinity(0))))      # 16 = the CPU share of a one-GPU box on this pool
         if cores > 1:
@@ -206,6 +244,140 @@ def launcher_rate(reads, n_total, n_gpus, force_rccl=False):
             "gather": gather[0] if gather else None}
 
 
+C5_FILES = ["3_5", "3_10", "3_20", "3_50", "5_10", "5_20", "5_50", "10_20", "10_50", "20_50", "2_5_10_20_set", "2_5_10_20_50_100_200_set",
+            "worm_chrI", "worm_chrII_1", "worm_chrII_2"]                     # test_multiple_TRs/test.sh:8-31, in its order
+
+
+def _child_env(extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MTR_LIB")}
+    env.update(GPU_MAX_HW_QUEUES="8")
+    if extra:
+        env.update(extra)
+    return env
+
+
+def _run_job(cmd, env, repeats=2, timeout=600):
+    """a command line as a fresh child process: best wall clock of `repeats`, its stdout's sha256 and line count, its -c block"""
+    best = None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=timeout)
+        except subprocess.TimeoutExpired:
+            return {"error": f"timeout after {timeout} s"}
+        dt = time.perf_counter() - t0
+        if p.returncode != 0:
+            return {"error": p.stderr.decode(errors="replace")[-300:], "returncode": p.returncode}
+        if best is None or dt < best["seconds"]:
+            err = p.stderr.decode(errors="replace")
+            block = {}
+            for ln in err.splitlines():
+                parts = ln.strip().split("\t")
+                if len(parts) == 2 and parts[0].replace(".", "", 1).isdigit():
+                    block[parts[1]] = float(parts[0])
+            gather = [ln for ln in err.splitlines() if "\tgather " in ln]
+            best = {"seconds": dt, "stdout_sha256": hashlib.sha256(p.stdout).hexdigest(), "stdout_lines": p.stdout.count(b"\n"),
+                    "c_block_s": block, "gather": gather[0] if gather else None}
+    if best.get("gather") and "exchange(s) over RCCL" in best["gather"]:
+        try:
+            best["exchanges_over_rccl"] = int(best["gather"].split("gather rccl, ")[1].split(" exchange")[0])
+        except Exception:
+            pass
+    return best
+
+
+def baseline_configs_through_the_command_line(n_gpus, with_per_file=True):
+    """BASELINE configs 2, 4 and 5 as the jobs users run: `mTR -c -g N` (the C host, one process, a run per GPU, the record tables gathered to the first GPU) as a
+    fresh child process each - wall clock incl. process start, HIP (and RCCL) initialisation, parsing, chaining and printing - with the stdout checked against a
+    committed known answer of the CPU oracle's command line / the reference's goldens.  Round 5's driver record had numbers for the headline and config 3 only."""
+    from mtr_amd import synth
+
+    exe = os.path.join(ROOT, "mtr_amd", "host", "mTR")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(exe), "mTR"], check=True)
+    env = _child_env({"MTR_HOST_TIMING": "1"})
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for cfg, n in (("c2", 1000), ("c4", 100000)):
+            try:
+                with open(os.path.join(ROOT, "tests", "golden", f"{cfg}_{n}_stdout.json")) as fh:
+                    known = json.load(fh)
+            except Exception:
+                known = None
+            fa = os.path.join(td, f"{cfg}.fa")
+            synth.write_fasta(fa, synth.make_reads(cfg, n, synth.CONFIGS[cfg][4]))
+            _run_job([exe, "-g", str(n_gpus), fa], env, repeats=1)                    # (page cache and the driver's memory pools warm)
+            j = _run_job([exe, "-c", "-g", str(n_gpus), fa], env)
+            if "error" not in j:
+                j.update(command=f"mTR -c -g {n_gpus} <fasta of the {n} reads of synth config {cfg}>", reads=n, gpus=n_gpus, reads_per_s=n / j["seconds"],
+                         matches_oracle=(known is not None and known["sha256"] == j["stdout_sha256"] and known["stdout_lines"] == j["stdout_lines"]) if known else None,
+                         known_answer=f"tests/golden/{cfg}_{n}_stdout.json (oracle/mtr_oracle_cli, pinned to the reference)" if known else None)
+            out[cfg] = j
+            os.unlink(fa)
+        # config 5: the 15 files of test_multiple_TRs (one read each, 2.6-140 kb), -p: longest first over the GPUs, one round, output in command-line order
+        files = [os.path.join(ROOT, "tests", "golden", "inputs", f"{n}.fasta") for n in C5_FILES]
+        if all(os.path.exists(f) for f in files):
+            want = hashlib.sha256()
+            for n in C5_FILES:
+                want.update(open(os.path.join(ROOT, "tests", "golden", f"{n}.p.stdout"), "rb").read())
+            _run_job([exe, "-p", "-g", str(n_gpus)] + files, env, repeats=1)
+            j = _run_job([exe, "-c", "-p", "-g", str(n_gpus)] + files, env)
+            if "error" not in j:
+                j.update(command=f"mTR -c -p -g {n_gpus} <the 15 files of test_multiple_TRs/test.sh:8-31>", files=len(files), gpus=n_gpus,
+                         sum_bases=int(sum(os.path.getsize(f) for f in files)), matches_reference_goldens=j["stdout_sha256"] == want.hexdigest(),
+                         known_answer="tests/golden/<file>.p.stdout (the reference compiled here, -p), concatenated in command-line order")
+                if with_per_file:
+                    per = {}
+                    for n, f in zip(C5_FILES, files):
+                        k = _run_job([exe, "-c", "-p", f], env, repeats=1)
+                        b = k.get("c_block_s", {})
+                        per[n] = {"wall_s": k.get("seconds"), "device_ms": round(1e3 * max(0.0, b.get("ranges", 0.0) + b.get("Computing periods", 0.0) - b.get("chaining", 0.0)), 3) if b else None}
+                    j["per_file_alone_on_one_gpu"] = per
+            out["c5"] = j
+    return out
+
+
+def host_ceiling_leg(n_reads=1000000):
+    """The host pipeline ALONE behind `mTR -g 8`: tests/null_engine.c answers every batch at once (two records per read), so what is timed is cutting, parsing + 2-bit
+    packing, the runs, the exchange, wire unpack + chaining + formatting and the writer - what one process must sustain for eight GPUs (8 x the headline rate = 2.3 M
+    reads/s).  No GPU is touched.  Stage costs: the same job with no records (parsing + packing + pipeline only) against the full one."""
+    from mtr_amd import synth
+    from tests import host_util
+
+    try:
+        reads = [c for _, c in synth.make_reads(WORKLOAD, 10000, seed=2)]
+        d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) and os.statvfs("/dev/shm").f_bavail * os.statvfs("/dev/shm").f_frsize > (5 << 30) else tempfile.gettempdir()
+        one = os.path.join(d, f"mtr_ceiling_{os.getpid()}_10k.fa")
+        big = os.path.join(d, f"mtr_ceiling_{os.getpid()}.fa")
+        synth.write_fasta(one, [(str(i), reads[i]) for i in range(len(reads))])
+        blob = open(one, "rb").read()
+        os.unlink(one)
+        with open(big, "wb") as fh:
+            for _ in range(max(1, n_reads // len(reads))):
+                fh.write(blob)
+        n = max(1, n_reads // len(reads)) * len(reads)
+        try:
+            full = host_util.host_ceiling(big, n, n_gpus=8, records=2, repeats=3)
+            bare = host_util.host_ceiling(big, n, n_gpus=8, records=0, repeats=2)
+            g1 = host_util.host_ceiling(big, n, n_gpus=1, records=2, repeats=2)
+        finally:
+            os.unlink(big)
+        cpu_full, cpu_bare = full["user_s"] + full["sys_s"], bare["user_s"] + bare["sys_s"]
+        return {"command": "mTR -g 8 <fasta> > /dev/null with MTR_LIB=tests/libmtr_null.so (every batch answered at once with 2 records per read)",
+                "reads": n, "fasta_bytes": len(blob) * (n // len(reads)), "seconds": full["seconds"], "reads_per_s": full["reads_per_s"],
+                "host_cores": full["host_cores"], "cores_used": full["cores_used"], "cpu_us_per_read": cpu_full / n * 1e6,
+                "reads_per_s_per_core_used": full["reads_per_s_per_core_used"],
+                "stages_cpu_us_per_read": {"cut + parse + 2-bit pack + batches through the runs": cpu_bare / n * 1e6,
+                                           "exchange + wire unpack + chain + format + write": (cpu_full - cpu_bare) / n * 1e6,
+                                           "of which system time (page faults, mmap)": full["sys_s"] / n * 1e6},
+                "without_records": {"seconds": bare["seconds"], "reads_per_s": bare["reads_per_s"]},
+                "one_gpu": {"seconds": g1["seconds"], "reads_per_s": g1["reads_per_s"], "cores_used": g1["cores_used"]},
+                "needed_for_8_gpus_at_the_headline_rate": "8 x value reads/s",
+                "note": "CPU only (no GPU touched).  Round 5: 238 k reads/s on 8 vCPU through the replay engine (one manager thread formatted a result, waited, wrote)"}
+    except Exception as ex:
+        return {"error": repr(ex)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,8 +387,8 @@ def main():
     ap.add_argument("--strong", default=None, choices=["c4"], help="strong scaling: one fixed read set split over the ranks")
     ap.add_argument("--strong-reads", type=int, default=100000)
     ap.add_argument("--cpu-sample", type=int, default=2000, help="reads timed on the CPU baseline (0 = skip); 2000 reads ~ 15 s on one core")
-    ap.add_argument("--config", default=None, choices=["c3"], help="a secondary line for another BASELINE config: c3 = 100 reads of unit 200 x 200 copies (L ~ 42 kb), -a on in the command-line leg")
-    ap.add_argument("--no-secondary", action="store_true", help="the default line without its secondary.c3 object (BASELINE config 3 measured in a child process)")
+    ap.add_argument("--config", default=None, choices=["c2", "c3"], help="a secondary line for another BASELINE config: c2 = 1 000 reads of unit 100 x 10 copies (L ~ 1.25 kb); c3 = 100 reads of unit 200 x 200 copies (L ~ 42 kb), -a on in the command-line leg")
+    ap.add_argument("--no-secondary", action="store_true", help="the default line without its secondary objects (BASELINE configs 2 and 3 measured in child processes, configs 2 / 4 / 5 through the command line, the host's ceiling)")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-cli", action="store_true")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip value_with_upload (profiling passes: only launches of the resident headline batch)")
@@ -239,18 +411,38 @@ def main():
     # (no process group exists yet).  Run after the timed steps it shared every GPU with a rank's idle context and waited for the driver to reclaim the
     # ranks' freed memory (2.8 s instead of 0.9 s in the two-rank rehearsal on one card).
     launcher_pre = None
+    pre = {}
+    t_start = time.time()
     if world > 1 and not a.no_cli and not a.strong and a.config is None:
-        marker = os.path.join(tempfile.gettempdir(), f"mtr_bench_launcher_{os.getppid()}.done")
+        # (the marker: named after the launcher's process and port, and only believed when it was written AFTER this process started - a stale one from a run that
+        #  died would let the other ranks initialise their GPUs while rank 0 is still timing)
+        marker = os.path.join(tempfile.gettempdir(), f"mtr_bench_launcher_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}.done")
         if rank == 0:
             try:
-                launcher_pre = launcher_rate([c for _, c in synth.make_reads(WORKLOAD, a.reads, seed=2)], 100000, world)
-            except Exception as ex:          # the bench line must not die of its optional leg
-                launcher_pre = {"error": repr(ex)[:300]}
+                os.remove(marker)
+            except OSError:
+                pass
+            try:
+                hreads = [c for _, c in synth.make_reads(WORKLOAD, a.reads, seed=2)]
+                launcher_pre = launcher_rate(hreads, 100000, world)
+                # the same job with every round forced onto RCCL (the default lets RCCL come up in the background: a 100 000-read job on 8 GPUs is over before it is up)
+                pre["launcher_rccl_forced"] = launcher_rate(hreads, 100000, world, force_rccl=True)
+                if not a.no_secondary:
+                    pre["baseline_configs_cli"] = baseline_configs_through_the_command_line(world, with_per_file=False)
+                    pre["host_ceiling"] = host_ceiling_leg()
+            except Exception as ex:          # the bench line must not die of its optional legs
+                launcher_pre = launcher_pre or {"error": repr(ex)[:300]}
+                pre.setdefault("error", repr(ex)[:300])
             with open(marker, "w") as fh:
                 fh.write("done")
         else:
             t_wait = time.perf_counter()
-            while not os.path.exists(marker) and time.perf_counter() - t_wait < 1500:
+            while time.perf_counter() - t_wait < 2400:
+                try:
+                    if os.path.getmtime(marker) >= t_start - 1.0:
+                        break
+                except OSError:
+                    pass
                 time.sleep(0.2)
     # MTR_BENCH_BACKEND=gloo: a rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share GPUs, the exchange
     # goes through host memory); the driver's runs use RCCL ("nccl"), one GPU per rank
@@ -287,8 +479,8 @@ def main():
         except Exception:
             pass
         reads = [c for _, c in synth.make_reads_range(a.strong, lo, hi, 4, ck)]
-    elif a.config == "c3":
-        reads = [c for _, c in synth.make_reads("c3", 100, seed=3 + rank)]
+    elif a.config is not None:
+        reads = [c for _, c in synth.make_reads(a.config, {"c2": 1000, "c3": 100}[a.config], seed=synth.CONFIGS[a.config][4] + rank)]
         n_job = len(reads) * world
     else:
         # every rank owns its own block of reads (weak scaling): same distribution, different seed
@@ -455,7 +647,7 @@ def main():
     dt_upload = None
     if world == 1:
         dt_kernel, _ = timed(a.steps, fetch=False)      # round 1's figure: the kernels alone, results left on the device
-        if not a.strong and a.config is None and not a.no_upload_leg:
+        if not a.strong and a.config is None and not a.no_upload_leg and NCTX >= 2:
             # the boundary handing over HOST buffers: every step takes a FRESH batch (three different read sets in turn) as concatenated base
             # codes + offsets + lengths in host memory (mtr_upload_batch: 2-bit packing on the calling thread + the copy to the device), runs
             # it and fetches its tables; the upload of step s+1 overlaps the kernels of step s (two contexts), as in the host pipeline
@@ -493,7 +685,9 @@ def main():
         phases = sorted({p for k in k2_ms for p in k if p.startswith("chain_")})
         phase_ms = {p[6:]: float(np.mean([k.get(p, 0.0) for k in k2_ms])) for p in phases}
         phase_ms_alone = {p[6:]: float(np.mean([k.get(p, 0.0) for k in sync_k2])) for p in phases} if sync_k2 else None
-        traffic, issue, prof_tag = profiled_counters()
+        prof, prof_tag = profiled_counters(a.config)
+        traffic = prof.get("k2_hbm_bytes_per_launch_fetch_x2") if prof else None
+        valu_insts = prof.get("SQ_INSTS_VALU_per_launch") if prof else None
         wire_bytes = len(eng.fetch_packed()[0]) if world == 1 else None
         if a.strong:
             workload = (f"{a.strong}: ONE set of {n_job} synthetic Nanopore reads (unit 50-200 x 10 copies, L ~ 2 kb), contiguous blocks of equal "
@@ -501,6 +695,9 @@ def main():
         elif a.config == "c3":
             workload = (f"c3 (BASELINE config 3 shape; the Badread sets are absent): {n_local} synthetic Nanopore reads per GPU, unit 200 x 200 copies, "
                         f"200-base flanks, mean L {np.mean([len(r) for r in reads]):.0f}")
+        elif a.config == "c2":
+            workload = (f"c2 (BASELINE config 2): {n_local} synthetic Nanopore reads per GPU, unit 100 x 10 copies, 100-base flanks, "
+                        f"mean L {np.mean([len(r) for r in reads]):.0f}, error profile sub 1.6/ins 9.0/del 3.8 %")
         else:
             workload = (f"{WORKLOAD}: {n_local} synthetic Nanopore reads per GPU, unit 100 x 10 copies, 500-base flanks, "
                         f"mean L {np.mean([len(r) for r in reads]):.0f}, error profile sub 1.6/ins 9.0/del 3.8 %")
@@ -544,15 +741,22 @@ def main():
                              "frac_computed_cells": computed_cells * OPS_PER_CELL / step_s / VALU_PEAK_LANE_OPS,
                              "note": "cells_reference = the reference's DP cells of the launch (memo_cells of them answered without a DP); by the driver-visible step, by a "
                                      "launch that has the GPU to itself, and the cells the kernels computed by the step"},
-            "issue": issue,
+            "issue": ({"by_lone_launch": (valu_insts * 2 / (1024 * launch_lone_s * 2.4e9)) if launch_lone_s else None,
+                       "by_step": valu_insts * 2 / (1024 * step_s * 2.4e9),
+                       "SQ_INSTS_VALU_per_launch": valu_insts,
+                       "note": "VALU issue utilisation = SQ_INSTS_VALU of one launch (committed PMC pass of THIS workload) x 2 cycles / (1 024 SIMDs x duration x 2.4 GHz), by the "
+                               "duration of a launch that has the GPU to itself and by the driver-visible step - not by the profiler's serialised launches (round 5's 0.170)"}
+                      if valu_insts else None),
+            "slot_time": slot_time(prof),
             "hbm": {"achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                     "frac_by_step": b_alg / step_s / 1e9 / HBM_PEAK_GBS,
                     "algorithmic_bytes_per_launch": b_alg, "spilled": "every DP of the reference is counted as spilled (SURVEY.md 8d's upper figure)"},
             "traffic": traffic, "traffic_source": prof_tag,
-            "note": "bound by VALU instruction issue: row-serial integer max-plus recurrence; issue = VALU issue utilisation (SQ_INSTS_VALU x 2 cycles / SIMD-cycles "
-                    "of the launch) of the profiled build; traffic = HBM bytes per launch of the whole chain (FETCH_SIZE x 2 + WRITE_SIZE, separate PMC passes)"})
+            "note": "bound by VALU instruction issue: row-serial integer max-plus recurrence; issue, slot_time and traffic (HBM bytes per launch of the whole chain, "
+                    "FETCH_SIZE x 2 + WRITE_SIZE, separate PMC passes) come from the committed profile of THIS workload and are null without one"})
         out = {
-            "metric": "reads/sec, 2 kb Nanopore synthetic" if a.config is None else "reads/sec, config 3 (unit 200 x 200 copies, L ~ 42 kb; secondary line)",
+            "metric": "reads/sec, 2 kb Nanopore synthetic" if a.config is None else "reads/sec, config 3 (unit 200 x 200 copies, L ~ 42 kb; secondary line)" if a.config == "c3"
+                      else "reads/sec, config 2 (1 000 reads, unit 100 x 10 copies, L ~ 1.25 kb; secondary line)",
             "value": value,
             "unit": "reads/s",
             "n_gpus": world,
@@ -628,19 +832,19 @@ def main():
             out["strong"] = {"ranks_seen": 1, "reads_per_rank": [n_local], "records": int(counts.sum()), "sha256": hx,
                              "matches_oracle": (known["sha256"] == hx) if known else None,
                              "known_answer": "tests/golden/c4_100k_wire.json (CPU oracle)" if known else None}
-        if a.config == "c3" and world == 1:
-            # the launch's record stream against the CPU oracle's known answer (tests/golden/make_c4_wire_hash.py --config c3 -n 100)
+        if a.config is not None and world == 1:
+            # the launch's record stream against the CPU oracle's known answer (tests/golden/make_c4_wire_hash.py --config c3 -n 100 / --config c2 -n 1000)
             data, counts = eng.fetch_packed()
             known = None
             try:
-                with open(os.path.join(ROOT, "tests", "golden", f"c3_{n_local}_wire.json")) as fh:
+                with open(os.path.join(ROOT, "tests", "golden", f"{a.config}_{n_local}_wire.json")) as fh:
                     known = json.load(fh)
             except Exception:
                 pass
             hx = hashlib.sha256(data).hexdigest()
             out["matches_oracle"] = (known["sha256"] == hx and known["records"] == int(counts.sum())) if known else None
             out["record_stream"] = {"records": int(counts.sum()), "wire_bytes": len(data), "sha256": hx,
-                                    "known_answer": f"tests/golden/c3_{n_local}_wire.json (CPU oracle, pinned to the reference)" if known else None}
+                                    "known_answer": f"tests/golden/{a.config}_{n_local}_wire.json (CPU oracle, pinned to the reference)" if known else None}
         if world == 1 and not a.no_latency:
             lat = []
             e2 = mtr_amd.Engine(device=local_rank)
@@ -659,6 +863,14 @@ def main():
             out["value_cli"] = ca.get("reads_per_s")
             out["cli"] = {"note": "mtr_amd/host/mTR -a <fasta> > /dev/null (alignment of every reported repeat on), wall clock incl. process start and HIP initialisation; best of 3",
                           "with_alignments": ca}
+        elif world == 1 and not a.no_cli and not a.strong and a.config == "c2":
+            for e in engs:
+                e.close()
+            engs.clear()
+            torch.cuda.empty_cache()
+            ca = cli_rate(reads, len(reads))
+            out["value_cli"] = ca.get("reads_per_s")
+            out["cli"] = {"note": "mtr_amd/host/mTR <fasta> > /dev/null, wall clock incl. process start and HIP initialisation; best of 3", "one_batch": ca}
         elif world == 1 and not a.no_cli and not a.strong:
             for e in engs:                              # the command line brings its own contexts: free this process's memory first
                 e.close()
@@ -677,6 +889,13 @@ def main():
             out["launcher"] = lr
             out["value_launcher"] = lr.get("reads_per_s")
             out["launcher_rccl_forced"] = launcher_rate(reads, 10 * len(reads), 1, force_rccl=True)
+            if not a.no_secondary:
+                # BASELINE configs 2, 4 and 5 as jobs of the command line (fresh child processes), and the host pipeline's ceiling behind eight GPUs (no GPU touched)
+                try:
+                    out["baseline_configs_cli"] = baseline_configs_through_the_command_line(1)
+                except Exception as ex:
+                    out["baseline_configs_cli"] = {"error": repr(ex)[:300]}
+                out["host_ceiling"] = host_ceiling_leg()
             try:        # the command line's own part: from the first device context (the runtime is up) to the end of the run
                 st = c10["stamps_s"]
                 own = st.get("run stopped", st["everything printed"]) - st["first device context created"]
@@ -684,7 +903,9 @@ def main():
             except Exception:
                 pass
         if world == 1 and a.cpu_sample > 0 and not a.strong:
-            out["cpu_baseline"] = cpu_baseline(reads, a.cpu_sample if a.config is None else min(a.cpu_sample, 6))     # (a config-3 read is ~2.6 s of CPU)
+            out["cpu_baseline"] = cpu_baseline(reads, a.cpu_sample if a.config is None else min(a.cpu_sample, 6 if a.config == "c3" else 1000))     # (a config-3 read is ~2.6 s of CPU)
+            if out["cpu_baseline"].get("ms_per_read_p50") and out.get("latency_ms_per_read_p50"):
+                out["latency_p50_vs_cpu"] = out["cpu_baseline"]["ms_per_read_p50"] / out["latency_ms_per_read_p50"]
             out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"]
             if "all_cores" in out["cpu_baseline"]:
                 out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline"]["all_cores"]["value"]
@@ -697,26 +918,29 @@ def main():
                 e.close()
             engs.clear()
             torch.cuda.empty_cache()
-            t0 = time.perf_counter()
-            try:
-                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "c3", "--steps", "24", "--warmup", "3", "--cpu-sample", str(min(a.cpu_sample, 6))]
-                                   + (["--no-cli"] if a.no_cli else []), capture_output=True, text=True, cwd=ROOT, timeout=420)
+            out["secondary"] = {}
+            for cfg, steps in (("c2", "40"), ("c3", "24")):
+                t0 = time.perf_counter()
                 try:
-                    sec = json.loads(p.stdout.strip().splitlines()[-1])
-                except Exception:
-                    sec = {"error": (p.stderr or p.stdout)[-400:], "returncode": p.returncode}
-            except subprocess.TimeoutExpired as ex:         # a stuck child must not take the driver-run line with it
-                sec = {"error": "timeout after 420 s: " + ((ex.stderr or b"")[-300:].decode(errors="replace") if isinstance(ex.stderr, bytes) else str(ex.stderr or "")[-300:])}
-            sec["wall_s"] = time.perf_counter() - t0
-            out["secondary"] = {"c3": sec}
+                    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", steps, "--warmup", "3", "--cpu-sample", str(min(a.cpu_sample, 6 if cfg == "c3" else 1000))]
+                                       + (["--no-cli"] if a.no_cli else []), capture_output=True, text=True, cwd=ROOT, timeout=420)
+                    try:
+                        sec = json.loads(p.stdout.strip().splitlines()[-1])
+                    except Exception:
+                        sec = {"error": (p.stderr or p.stdout)[-400:], "returncode": p.returncode}
+                except subprocess.TimeoutExpired as ex:         # a stuck child must not take the driver-run line with it
+                    sec = {"error": "timeout after 420 s: " + ((ex.stderr or b"")[-300:].decode(errors="replace") if isinstance(ex.stderr, bytes) else str(ex.stderr or "")[-300:])}
+                sec["wall_s"] = time.perf_counter() - t0
+                out["secondary"][cfg] = sec
     for e in engs:
         e.close()
     engs.clear()
     if rank == 0 and launcher_pre is not None:
         out["launcher"] = launcher_pre
         out["value_launcher"] = launcher_pre.get("reads_per_s")
+        out.update(pre)                                 # launcher_rccl_forced, baseline_configs_cli, host_ceiling: measured before any rank touched its GPU
         try:
-            os.remove(os.path.join(tempfile.gettempdir(), f"mtr_bench_launcher_{os.getppid()}.done"))
+            os.remove(os.path.join(tempfile.gettempdir(), f"mtr_bench_launcher_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}.done"))
         except OSError:
             pass
     if rank == 0:

@@ -837,6 +837,12 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     // estimates from the bases of the batch (2 kb reads have ~0.11 ranges, 0.02 alignments, 0.002 (range, k) searches and
     // revisions per base; 42 kb reads fewer); a batch that has more items than wavefronts only takes longer.
     auto capped = [&](int g, int64_t per_bases) { return (int)std::min<int64_t>(g, std::max<int64_t>(64, sumL / per_bases + 64)); };
+    // wavefronts per CU of the chain's service kernels (per block / per revision: a few dependent memory round trips per item and next to no instructions).  A
+    // persistent grid holds its wavefront slots for the kernel's whole duration: sized by the chip (32 per CU) these kernels held a sixth of the step's slot time
+    // for 3 % of its instructions.  MTR_SERVICE_WPC / MTR_SELECT_WPC (development) override.
+    static const int service_wpc = getenv("MTR_SERVICE_WPC") ? atoi(getenv("MTR_SERVICE_WPC")) : 32;
+    static const int select_wpc = getenv("MTR_SELECT_WPC") ? atoi(getenv("MTR_SELECT_WPC")) : 16;
+    static const int polish_wpc = getenv("MTR_POLISH_WPC") ? atoi(getenv("MTR_POLISH_WPC")) : 16;
     hipLaunchKernelGGL(mtr_k_items, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)ctx->d_rcount, s);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(mtr_k_item_table, dim3((unsigned)std::min(n, 4096)), dim3(256), 0, ctx->stream, a, s);
@@ -858,7 +864,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(mtr_k_walks_k, dim3((unsigned)capped(ww, 32)), dim3(64), 0, ctx->stream, aw, s);
             HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL(mtr_k_gather, dim3((unsigned)capped(ctx->n_cu * 32, 64)), dim3(64), 0, ctx->stream, a, s);      // (19 VGPRs, no LDS: eight wavefronts per SIMD hide its loads)
+            hipLaunchKernelGGL(mtr_k_gather, dim3((unsigned)capped(ctx->n_cu * service_wpc, 64)), dim3(64), 0, ctx->stream, a, s);      // (19 VGPRs, no LDS: eight wavefronts per SIMD hide its loads)
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(evp[3], ctx->stream));       // unit search (tables, seeds, walks) + the alignment items
@@ -878,7 +884,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         }
         if (s.quad_min > 0) HIPCHK(hipMemsetAsync(ctx->d_st_bincnt, 0, (size_t)ST_NBINS * 4, ctx->stream));     // the revisions are sorted next
         HIPCHK(hipEventRecord(evp[4], ctx->stream));       // two-parameter alignments
-        hipLaunchKernelGGL(mtr_k_select, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
+        hipLaunchKernelGGL(mtr_k_select, dim3((unsigned)capped(std::min(waves, ctx->n_cu * select_wpc), 64)), dim3(64), 0, ctx->stream, a, s);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(mtr_k_select_slow, dim3((unsigned)std::min(waves, 64)), dim3(64), 0, ctx->stream, a, s);      // (blocks the kernel above left: normally none)
         HIPCHK(hipGetLastError());
@@ -894,10 +900,10 @@ static mtr_status launch_staged(mtr_ctx *ctx)
                 int wp = pick_waves(ctx, std::max(n * 8, ctx->n_cu * 16), waves_per_cu(), pw, &tw);
                 if (tw > ctx->scratch_bytes) wp = std::min(wp, waves);
                 ap.scratch_per_wave = pw;
-                hipLaunchKernelGGL(mtr_k_polish, dim3((unsigned)capped(wp, 256)), dim3(64), 0, ctx->stream, ap, s);
+                hipLaunchKernelGGL(mtr_k_polish, dim3((unsigned)capped(std::min(wp, ctx->n_cu * polish_wpc), 256)), dim3(64), 0, ctx->stream, ap, s);
                 HIPCHK(hipGetLastError());
             }
-            hipLaunchKernelGGL(mtr_k_rev_share, dim3((unsigned)capped(ctx->n_cu * 32, 64)), dim3(64), 0, ctx->stream, a, s);
+            hipLaunchKernelGGL(mtr_k_rev_share, dim3((unsigned)capped(ctx->n_cu * service_wpc, 64)), dim3(64), 0, ctx->stream, a, s);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(mtr_k_qbins, dim3(1), dim3(1024), 0, ctx->stream, s, 1);
             HIPCHK(hipGetLastError());
@@ -912,7 +918,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         } else hipLaunchKernelGGL(mtr_k_revise, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(evp[6], ctx->stream));       // revisions
-        hipLaunchKernelGGL(mtr_k_finish, dim3((unsigned)capped(ctx->n_cu * 32, 64)), dim3(64), 0, ctx->stream, a, s);
+        hipLaunchKernelGGL(mtr_k_finish, dim3((unsigned)capped(ctx->n_cu * service_wpc, 64)), dim3(64), 0, ctx->stream, a, s);
         HIPCHK(hipGetLastError());
         return MTR_OK;
     };

@@ -60,8 +60,9 @@ NOT_CHAIN = ("mtr_k_reads", "mtr_k_wire")
 
 def main():
     out, tag = sys.argv[1], sys.argv[2]
-    s = {"tag": tag, "kernel_src_sha": kernel_sources_sha(),
-         "command": "bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-latency --no-cli under rocprofv3 (one pass per counter group)"}
+    config = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] else None
+    s = {"tag": tag, "config": config or "headline2k", "kernel_src_sha": kernel_sources_sha(),
+         "command": "bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-latency --no-cli" + (f" --config {config}" if config else "") + " under rocprofv3 (one pass per counter group)"}
     stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
     dur_ms = {}
     if stats:

@@ -42,9 +42,9 @@ def main():
     ap.add_argument("--config", default="c4", help="c4 (seed 4); c3 = BASELINE config 3's shape, seed 3 (bench.py's secondary.c3: -n 100)")
     a = ap.parse_args()
     from mtr_amd import synth
-    seed = {"c4": 4, "c3": 3}[a.config]
+    seed = synth.CONFIGS[a.config][4]          # (c4: 4, c3: 3, c2: 1)
     READS = synth.make_reads(a.config, a.n, seed)
-    step = 500 if a.config == "c4" else 2
+    step = 2 if a.config == "c3" else 100 if a.config == "c2" else 500
     jobs = [(lo, min(lo + step, a.n)) for lo in range(0, a.n, step)]
     h = hashlib.sha256()
     total_bytes = total_rec = 0

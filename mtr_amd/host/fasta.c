@@ -114,6 +114,8 @@ typedef struct {
     int64_t cap_reads, cap_codes, cap_words, n_codes;
     int max_reads; int64_t max_bases;
     int64_t hint_codes;                    /* bytes of the chunk still to parse when the batch was opened: its bases cannot be more */
+    int pack_only;                         /* no code array: the bases go straight into the 2-bit image (a run without -a / -B never looks at the codes) */
+    uint32_t pend; int n_pend;             /* pack_only: the bases of the read that do not fill a word yet (first base in the top bits) */
 } builder;
 
 static mtrh_batch *batch_new(void)
@@ -143,6 +145,19 @@ static uint8_t *codes_room(builder *B, int64_t have, int64_t more)
     return b->codes + B->n_codes;
 }
 
+/* pack_only: room for `more` further bases of the read being parsed (its words so far: b->n_words .. the write position), plus the read's closing words */
+static uint32_t *words_room(builder *B, int64_t wpos, int64_t more)
+{
+    mtrh_batch *b = B->cur;
+    const int64_t need = wpos + more / 16 + 8;
+    if (need > B->cap_words) {
+        int64_t c = B->cap_words ? B->cap_words * 2 : (B->hint_codes / 12 > (1 << 18) ? B->hint_codes / 12 : (1 << 18));
+        while (c < need) c *= 2;
+        b->packed = (uint32_t *)xrealloc(b->packed, sizeof(uint32_t) * (size_t)c); B->cap_words = c;
+    }
+    return b->packed;
+}
+
 static void read_done(builder *B, int64_t len, const char *id, int32_t id_len)
 {
     mtrh_batch *b = B->cur;
@@ -154,6 +169,17 @@ static void read_done(builder *B, int64_t len, const char *id, int32_t id_len)
         B->cap_reads = c;
     }
     const int64_t nw = mtr_packed_words((int32_t)len);
+    if (B->pack_only) {
+        /* the full words are written; the partial one (zero if the length is a multiple of 16) and three zero words close the read (mtr_hip.h: the image) */
+        uint32_t *w = words_room(B, b->n_words + len / 16, 0) + b->n_words + len / 16;
+        w[0] = B->n_pend ? B->pend : 0u; w[1] = 0; w[2] = 0; w[3] = 0;
+        B->pend = 0; B->n_pend = 0;
+        const int i = b->n++;
+        b->lens[i] = (int32_t)len; b->offs[i] = B->n_codes; b->woff[i] = b->n_words; b->ids[i] = id; b->id_lens[i] = id_len;
+        b->n_words += nw; B->n_codes += len;
+        if (b->n >= B->max_reads || B->n_codes >= B->max_bases) { B->hint_codes = B->hint_codes > B->n_codes ? B->hint_codes - B->n_codes : 0; builder_open(B); }
+        return;
+    }
     if (b->n_words + nw > B->cap_words) {
         int64_t c = B->cap_words ? B->cap_words * 2 : (B->hint_codes / 12 > (1 << 18) ? B->hint_codes / 12 : (1 << 18));      /* (bases / 16 + 4 words per read: a twelfth of the bytes covers reads of 200 bases and more) */
         while (c < b->n_words + nw) c *= 2;
@@ -166,10 +192,88 @@ static void read_done(builder *B, int64_t len, const char *id, int32_t id_len)
     if (b->n >= B->max_reads || B->n_codes >= B->max_bases) { B->hint_codes = B->hint_codes > B->n_codes ? B->hint_codes - B->n_codes : 0; builder_open(B); }
 }
 
-mtrh_batch *mtrh_parse_chunk(const mtrh_file *f, size_t begin, size_t end, int max_reads, int64_t max_bases)
+/* ---- pack_only: a window's bases straight into the read's 2-bit words ---------------------------------------------------------------------------
+ * Sixteen characters at a time where the CPU has SSSE3 (every x86-64 since 2006; anything else takes the byte loop): one table look-up by the low nibble of the
+ * upper-cased character says which letter a base must be ('A' 1, 'C' 3, 'T' 4, 'G' 7 - the four low nibbles differ) and its code; a block with any other
+ * character - the line's end included - goes to the byte loop, which stops exactly where the reader of handle_one_file.c:169-188 stops.  Two multiply-adds fold
+ * the sixteen codes into one word, first base in the top bits (mtr_hip.h).  Parsing + packing was 2.7 of the host's 4.6 us of CPU per 2 kb read (bench.py:
+ * host_ceiling): a byte at a time into a code array, then a second pass over it to pack. */
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("ssse3"))) static const unsigned char *pack16_ssse3(const unsigned char *s, const unsigned char *wend, uint32_t *out, int64_t *n_out)
+{   /* whole blocks of 16 valid bases from s: their words to out[0..], their number to *n_out; returns where it stopped */
+    const char X = (char)0xFF;                           /* no upper-cased character equals it (bit 5 is cleared): NUL and the space must not pass for nibble 0 */
+    const __m128i lut_letter = _mm_setr_epi8(X, 'A', X, 'C', 'T', X, X, 'G', X, X, X, X, X, X, X, X);
+    const __m128i lut_code = _mm_setr_epi8(0, 0, 0, 1, 3, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m128i up = _mm_set1_epi8((char)0xDF), lo4 = _mm_set1_epi8(0x0F);
+    const __m128i m1 = _mm_set1_epi16(0x0104);          /* (c0, c1) -> 4 c0 + c1 */
+    const __m128i m2 = _mm_set1_epi32(0x00010010);      /* (p0, p1) -> 16 p0 + p1 */
+    const __m128i gather = _mm_setr_epi8(12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    int64_t n = 0;
+    while (wend - s >= 16) {
+        const __m128i v = _mm_loadu_si128((const __m128i *)s);
+        const __m128i u = _mm_and_si128(v, up);
+        const __m128i nib = _mm_and_si128(u, lo4);
+        if (_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_shuffle_epi8(lut_letter, nib), u)) != 0xFFFF) break;
+        const __m128i c = _mm_shuffle_epi8(lut_code, nib);
+        const __m128i q = _mm_madd_epi16(_mm_maddubs_epi16(c, m1), m2);
+        out[n >> 4] = (uint32_t)_mm_cvtsi128_si32(_mm_shuffle_epi8(q, gather));
+        s += 16; n += 16;
+    }
+    *n_out = n;
+    return s;
+}
+#endif
+
+/* the bases of one window [s, wend) (up to the first character that is not a base) behind the read's `n` bases so far; returns where it stopped */
+static const unsigned char *append_packed(builder *B, const unsigned char *s, const unsigned char *wend, int64_t n)
+{
+    mtrh_batch *b = B->cur;
+    uint32_t *w = words_room(B, b->n_words + n / 16, wend - s) + b->n_words + n / 16;      /* the word the next base goes to */
+    uint32_t pend = B->pend; int p = B->n_pend;
+#if defined(__x86_64__)
+    static int have = -1;
+    if (have < 0) have = __builtin_cpu_supports("ssse3") ? 1 : 0;
+    if (have && wend - s >= 16) {
+        if (p == 0) {                                     /* word-aligned: the blocks' words go where they belong */
+            int64_t got = 0;
+            s = pack16_ssse3(s, wend, w, &got);
+            w += got >> 4;
+        } else {
+            /* behind p pending bases every word of 16 new bases straddles two words of the image */
+            uint32_t tmp[64];
+            while (wend - s >= 16) {
+                const unsigned char *lim = wend - s > 1024 ? s + 1024 : wend;       /* tmp holds the words of 1 024 bases */
+                int64_t got = 0;
+                const unsigned char *s2 = pack16_ssse3(s, lim, tmp, &got);
+                for (int64_t q = 0; q < (got >> 4); q++) { *w++ = pend | (tmp[q] >> (2 * p)); pend = tmp[q] << (32 - 2 * p); }
+                const int stopped = lim - s2 >= 16;         /* a block that is not sixteen bases: the byte loop takes it from here */
+                s = s2;
+                if (stopped || got == 0) break;
+            }
+        }
+    }
+#endif
+    uint8_t c;
+    while (s < wend && (c = code_of[*s]) <= 3) {
+        pend |= (uint32_t)c << (30 - 2 * p);
+        if (++p == 16) { *w++ = pend; pend = 0; p = 0; }
+        s++;
+    }
+    B->pend = pend; B->n_pend = p;
+    return s;
+}
+
+static mtrh_batch *parse_chunk(const mtrh_file *f, size_t begin, size_t end, int max_reads, int64_t max_bases, int pack_only);
+mtrh_batch *mtrh_parse_chunk(const mtrh_file *f, size_t begin, size_t end, int max_reads, int64_t max_bases) { return parse_chunk(f, begin, end, max_reads, max_bases, 0); }
+/* the same without the code array (mtrh_batch.codes = NULL): for runs that only upload the 2-bit image (no -a rows, no -B state) */
+mtrh_batch *mtrh_parse_chunk_packed(const mtrh_file *f, size_t begin, size_t end, int max_reads, int64_t max_bases) { return parse_chunk(f, begin, end, max_reads, max_bases, 1); }
+
+static mtrh_batch *parse_chunk(const mtrh_file *f, size_t begin, size_t end, int max_reads, int64_t max_bases, int pack_only)
 {
     init_codes();
     builder B; memset(&B, 0, sizeof B);
+    B.pack_only = pack_only;
     B.max_reads = max_reads > 0 ? max_reads : 16384; B.max_bases = max_bases > 0 ? max_bases : ((int64_t)512 << 20);
     B.hint_codes = (int64_t)(end - begin) < B.max_bases ? (int64_t)(end - begin) : B.max_bases;
     builder_open(&B);
@@ -179,7 +283,7 @@ mtrh_batch *mtrh_parse_chunk(const mtrh_file *f, size_t begin, size_t end, int m
                                                         * precede it and join that record (:213-221); a chunk that starts
                                                         * inside the file starts at a header */
     int64_t n = 0;                                     /* bases of the record being read */
-    uint8_t *dst = codes_room(&B, 0, MTRH_BLK);
+    uint8_t *dst = pack_only ? NULL : codes_room(&B, 0, MTRH_BLK);
     int end_status = MTRH_END_NONE; char bad = 0;
     while (p < e) {
         /* one fgets window: up to 4095 characters, through the newline if it comes earlier */
@@ -195,14 +299,20 @@ mtrh_batch *mtrh_parse_chunk(const mtrh_file *f, size_t begin, size_t end, int m
             if (n == 0) { end_status = MTRH_END_EMPTY; break; }
             read_done(&B, n, id ? id : "", id ? id_len : 0);
             id = nid; id_len = nid_len; n = 0;
-            dst = codes_room(&B, 0, MTRH_BLK);
+            if (!pack_only) dst = codes_room(&B, 0, MTRH_BLK);
             p = wend;
             continue;
         }
-        dst = codes_room(&B, n, (int64_t)wl) + n;
-        const unsigned char *s = p; uint8_t c; uint8_t *d = dst;
-        while (s < wend && (c = code_of[*s]) <= 3) { *d++ = c; s++; }
-        n += (int64_t)(d - dst);
+        const unsigned char *s = p;
+        if (pack_only) {
+            s = append_packed(&B, p, wend, n);
+            n += (int64_t)(s - p);
+        } else {
+            dst = codes_room(&B, n, (int64_t)wl) + n;
+            uint8_t c; uint8_t *d = dst;
+            while (s < wend && (c = code_of[*s]) <= 3) { *d++ = c; s++; }
+            n += (int64_t)(d - dst);
+        }
         if (MTR_MAX_INPUT_LENGTH <= n) { end_status = MTRH_END_TOOLONG; break; }   /* the reference stops at the base that reaches the limit */
         if (s < wend && code_of[*s] == 0xFF) { end_status = MTRH_END_BADCHAR; bad = (char)*s; break; }
         p = wend;

@@ -108,6 +108,8 @@ typedef struct mtrh_batch {
 } mtrh_batch;
 /* parse [begin, end) of the file (a piece of mtrh_plan_chunks) into batches of at most max_reads reads / max_bases bases */
 mtrh_batch *mtrh_parse_chunk(const mtrh_file *f, size_t begin, size_t end, int max_reads, int64_t max_bases);
+/* the same without the code array (codes = NULL, offs = running base counts): the bases go straight into the 2-bit image, 16 characters at a time (fasta.c) */
+mtrh_batch *mtrh_parse_chunk_packed(const mtrh_file *f, size_t begin, size_t end, int max_reads, int64_t max_bases);
 void mtrh_batch_free(mtrh_batch *b);       /* the whole list */
 
 /* ---- chaining.cpp:243-363 with alignments taken in insertion order ------------------------------------------------ */

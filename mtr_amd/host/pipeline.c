@@ -122,7 +122,9 @@ static void *parser_main(void *arg)
         const int idx = r->next_parse++;
         pthread_mutex_unlock(&r->mu);
         const chunk_t *c = &r->chunks[r->list[idx]];
-        mtrh_batch *b = mtrh_parse_chunk(&r->files[c->file], c->begin, c->end, BATCH_READS, BATCH_BASES);
+        /* the code array (a byte per base) is only read by -a (the rows of an alignment block) and -B (the file state): every other run parses into the image alone */
+        mtrh_batch *b = (r->o.print_alignment || r->o.file_order) ? mtrh_parse_chunk(&r->files[c->file], c->begin, c->end, BATCH_READS, BATCH_BASES)
+                                                                  : mtrh_parse_chunk_packed(&r->files[c->file], c->begin, c->end, BATCH_READS, BATCH_BASES);
         pthread_mutex_lock(&r->mu);
         r->parsed[idx] = b; r->pstate[idx] = 1;
         pthread_cond_broadcast(&r->cv_parse);

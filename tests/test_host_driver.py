@@ -266,7 +266,7 @@ def test_an_overlong_record_at_the_start_of_a_chunk_names_the_record_before_it(c
     lib.mtrh_file_close(C.byref(f))
 
 
-@pytest.mark.parametrize("where,n", [("parser", 3), ("parser", 8), ("device", 2), ("device", 4), ("printer", 1), ("printer", 2)])
+@pytest.mark.parametrize("where,n", [("parser", 3), ("parser", 6), ("device", 2), ("device", 4), ("printer", 1), ("printer", 2)])
 def test_a_failed_allocation_in_a_worker_thread_ends_the_run_like_a_device_error(cli, tables, tmp_path, where, n):
     """alloc.c: the n-th allocation of a parser / device / printer thread fails (MTR_TEST_FAIL_ALLOC).  No exit() inside the thread and
     no hang: what was printed before is a prefix of the reference's stdout, the message is on stderr, the status is 1."""
@@ -276,3 +276,64 @@ def test_a_failed_allocation_in_a_worker_thread_ends_the_run_like_a_device_error
     assert p.returncode == 1, (p.returncode, p.stderr.decode()[-300:])
     assert b"cannot allocate" in p.stderr
     assert want.startswith(p.stdout) and len(p.stdout) < len(want)
+
+
+def test_parsing_straight_into_the_image_equals_parsing_through_codes(tmp_path):
+    """mtrh_parse_chunk_packed (16 characters at a time into the 2-bit image, no code array) against mtrh_parse_chunk on the hostile files, on wrapped lines of
+    every width around the block size, on long lines that cross the 4 095-character windows, and on reads whose bases arrive behind 1 .. 15 pending ones"""
+    lib = C.CDLL(os.path.join(hu.HOST, "libmtr_host.so"))
+    lib.mtrh_plan_chunks.restype = C.POINTER(C.c_size_t)
+    lib.mtrh_plan_chunks.argtypes = [C.POINTER(File), C.c_int, C.POINTER(C.c_int)]
+    for fn in (lib.mtrh_parse_chunk, lib.mtrh_parse_chunk_packed):
+        fn.restype = C.POINTER(Batch)
+        fn.argtypes = [C.POINTER(File), C.c_size_t, C.c_size_t, C.c_int, C.c_int64]
+    lib.mtrh_batch_free.argtypes = [C.POINTER(Batch)]
+    rng = np.random.default_rng(16)
+    cases = dict(FASTA_CASES)
+    for width in (1, 7, 15, 16, 17, 31, 32, 33, 60, 70, 80, 1023, 1024, 1025):
+        recs = []
+        for r in range(6):
+            n = int(rng.integers(1, 5000))
+            seq = "".join("ACGTacgt"[int(x)] for x in rng.integers(0, 8, n))
+            recs.append(f">w{width}_{r} x\n" + "\n".join(seq[i:i + width] for i in range(0, n, width)) + "\n")
+        cases[f"wrapped_{width}"] = "".join(recs).encode()
+    cases["long_lines"] = b"".join(b">L%d\n" % k + bytes(rng.choice(list(b"ACGT"), int(n)).astype(np.uint8)) + b"\n" for k, n in enumerate((4094, 4095, 4096, 4097, 8190, 8191, 12300, 33)))
+    cases["nul_laden"] = b"".join(b">Z%d\n" % k + bytes(rng.choice(list(b"ACGT"), int(n))) + b"\n" for k, n in enumerate((4094, 4095, 4096)))     # (int64 items: seven NULs behind every base)
+    cases["every_byte"] = b">e\n" + b"".join(b"ACGTACGTACGTACG" + bytes([v]) + b"ACGT\n" for v in range(256) if v not in (10, 13, 0)) + b">f\nAC\n"
+    cases["space_and_nul"] = b">s\n" + b"ACGT" * 4 + b" " + b"ACGT" * 4 + b"\n"
+    for v in range(256):                                     # every byte value inside a block of sixteen, at every position of the block
+        cases[f"byte_{v}"] = b">b\n" + b"".join(b"ACGTACGTACGTACGTACGT"[:q] + bytes([v]) + b"ACGTACGTACGTACGTACGTAC"[:21 - q] + b"\n" for q in (0, 5, 15, 16)) + b">c\nAC\n"
+    cases["bad_in_block"] = b">a\n" + b"ACGT" * 10 + b"N" + b"ACGT" * 10 + b"\n>b\nAC\n"
+    cases["cr_in_block"] = b">a\r\n" + b"ACGT" * 9 + b"\r\n" + b"GG" * 40 + b"\r\n>b\r\nAC\r\n"
+    cases["nul_in_block"] = b">a\n" + b"ACGT" * 5 + b"\0" + b"TTTT" * 8 + b"\n" + b"CC" * 20 + b"\n"
+    n_reads = 0
+    for name, data in cases.items():
+        path = str(tmp_path / f"{name}.fa")
+        with open(path, "wb") as fh:
+            fh.write(data)
+        for n_target in ((1,) if name.startswith("byte_") else (1, 2, 5)):
+            f = File()
+            assert lib.mtrh_file_open(C.byref(f), path.encode()) == 0
+            nc = C.c_int()
+            off = lib.mtrh_plan_chunks(C.byref(f), n_target, C.byref(nc))
+            for c in range(nc.value):
+                for max_reads in (3, 1000):
+                    ha = lib.mtrh_parse_chunk(C.byref(f), off[c], off[c + 1], max_reads, 1 << 40)
+                    hb = lib.mtrh_parse_chunk_packed(C.byref(f), off[c], off[c + 1], max_reads, 1 << 40)
+                    a, b = ha, hb
+                    while a or b:
+                        assert bool(a) == bool(b), (name, n_target, c)
+                        x, y = a.contents, b.contents
+                        assert (x.n, x.n_words, x.end, x.bad_char, x.end_id_len) == (y.n, y.n_words, y.end, y.bad_char, y.end_id_len), (name, n_target, c)
+                        assert not y.codes
+                        if x.n:
+                            assert list(x.lens[:x.n]) == list(y.lens[:x.n]) and list(x.woff[:x.n]) == list(y.woff[:x.n]) and list(x.offs[:x.n]) == list(y.offs[:x.n])
+                            assert list(x.id_lens[:x.n]) == list(y.id_lens[:x.n])
+                            assert [C.string_at(x.ids[i], x.id_lens[i]) for i in range(x.n)] == [C.string_at(y.ids[i], y.id_lens[i]) for i in range(x.n)]
+                            wa = np.ctypeslib.as_array(x.packed, shape=(x.n_words,)); wb = np.ctypeslib.as_array(y.packed, shape=(y.n_words,))
+                            assert np.array_equal(wa, wb), (name, n_target, c)
+                            n_reads += x.n
+                        a, b = x.next, y.next
+                    lib.mtrh_batch_free(ha); lib.mtrh_batch_free(hb)
+            lib.mtrh_file_close(C.byref(f))
+    assert n_reads > 500

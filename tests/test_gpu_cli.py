@@ -1,6 +1,7 @@
 """The drop-in command line on the GPU box: mtr_amd/host/mTR [-a] [-p] <fasta> must print byte for byte what the
 reference printed (tests/golden/*.stdout, isolated semantics) — FASTA in, report/alignment lines out."""
 import glob
+import json
 import os
 import subprocess
 
@@ -91,6 +92,10 @@ def test_reference_front_end_with_the_binding_of_integration_md():
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/mTR_ref_gpu was not built (needs /root/reference at build time)")
     cases = [(n, m) for n in ("3_5", "10_50", "2_5_10_20_set", "worm_chrI") for m in ("default", "p", "a")] + [("synth_c2", "default"), ("synth_c4", "default"), ("synth_2k", "default")]
+    # which cases hold a read whose chain depends on the order of its alignments (tests/golden/tied_chains.py decides that on the CPU from the golden G4 records:
+    # the sweep under ten orders of a read's records): only those may differ from the golden stdout, and only by a tie; every other case is exact
+    with open(os.path.join(gu.GOLDEN, "tied_chain_cases.json")) as fh:
+        tied_cases = set(json.load(fh)["reads_with_an_order_dependent_chain"])
     exact = tied_reads = 0
     for name, mode in cases:
         p = subprocess.run([exe, *FLAGS[mode], gu.input_path(name)], capture_output=True)
@@ -99,6 +104,7 @@ def test_reference_front_end_with_the_binding_of_integration_md():
         if p.stdout == ref:
             exact += 1
             continue
+        assert f"{name}.{'p' if mode == 'p' else 'default'}" in tied_cases, (name, mode, "no read of this case has an order-dependent chain: its stdout must be the reference's byte for byte")
         reads = gu.read_fasta(gu.input_path(name))
         cap = gu.capture_by_read(name, "p" if mode == "p" else "default")
         inserted = {}
@@ -113,7 +119,8 @@ def test_reference_front_end_with_the_binding_of_integration_md():
             stray = [ln for ln in got[rid] if ln not in inserted[rid]]
             assert not stray, (name, mode, rid, "a printed repeat is not a record the reference inserted", stray[:2])
             assert sum(ln[5] for ln in got[rid]) == sum(ln[5] for ln in want[rid]), (name, mode, rid, "the printed chain is not a tie of the reference's")
-    assert exact >= len(cases) // 2, f"only {exact} of {len(cases)} identical"
+    n_must = sum(1 for n, m in cases if f"{n}.{'p' if m == 'p' else 'default'}" not in tied_cases)
+    assert exact >= n_must and n_must >= 8, f"only {exact} of {len(cases)} identical ({n_must} have no order-dependent chain)"
 
 
 def test_cli_reports_the_engine_library_it_bound(cli):

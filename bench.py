@@ -25,6 +25,13 @@ wire-form tables go device-to-device to rank 0 over RCCL (mtr_export_packed_devi
 config 4 — one set of 100 000 mixed-unit reads, contiguous blocks balanced by sum of lengths; rank 0 checks the sha256 of
 the gathered stream against the known answer of the CPU oracle (tests/golden/c4_100k_wire.json) and reports ranks_seen.
 
+Round 6: every BASELINE config is in the default line, each with its own evidence - `secondary.c2` / `secondary.c3` (configs 2 and 3 as resident-batch steps in child
+processes, record streams against the oracle's known answers), `baseline_configs_cli` (configs 2, 4 and 5 as jobs of `mTR -c -g N`, fresh child processes, stdout
+against committed known answers), `host_ceiling` (the host pipeline alone behind eight null GPUs), `cpu_baseline.ms_per_read_p50` (the reference, one read per
+process); `roofline.issue` by the lone launch and by the step, `roofline.slot_time` = wavefront-slot time per kernel, `roofline.traffic` - all three from the
+committed PMC passes of THE SAME workload (profiles/pmc_latest.json for the headline, profiles/pmc_c3.json for config 3), null otherwise.  At N > 1 rank 0 measures
+`value_launcher` (default and with every round forced onto RCCL), `baseline_configs_cli` and `host_ceiling` as child processes BEFORE any rank touches a GPU.
+
 roofline: a launch is the staged chain (k3_staged.hip.inc: ranges -> [unit search -> alignments -> selection -> revisions] for the ranges of wide
 windows, then for the ranges their records leave -> replay, one stream, no host round trip); its duration and the durations of its phases are measured with HIP events on the launch stream
 inside the timed region (mtr_get_kernel_times), the dominant phases are the wrap-around DP kernels mtr_k_dp2_quads (alignments) and
@@ -105,7 +112,7 @@ def slot_time(prof):
     tot = sum(ks.values())
     if tot <= 0:
         return None
-    service = ("mtr_k_gather", "mtr_k_select", "mtr_k_select_slow", "mtr_k_rev_share", "mtr_k_finish", "mtr_k_polish", "mtr_k_replay", "mtr_k_pass_mark", "mtr_k_item_table")
+    service = ("mtr_k_gather", "mtr_k_select", "mtr_k_rev_share", "mtr_k_finish", "mtr_k_polish", "mtr_k_replay", "mtr_k_pass_mark", "mtr_k_item_table")
     return {"sum_wave_cycles": tot, "ms_on_4096_slots_at_2.4GHz": tot / (4096 * 2.4e9) * 1e3,
             "service_kernels_wave_cycles": sum(v for k, v in ks.items() if k in service),
             "service_kernels": list(service),

@@ -752,7 +752,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         s.sorted_cap = s.dp_cap + 4 * ST_QCLASSES;
     }
     ST_ALLOC(ensure_dev(ctx, ctx->d_st_arena, (size_t)s.arena_cap));
-    ST_ALLOC(ensure_dev(ctx, ctx->d_st_kc, (size_t)s.kc_cap * 8 * 3));      /* (the block list; behind it the list of the blocks with a revision due and the one of mtr_k_select_slow) */ ST_ALLOC(ensure_dev(ctx, ctx->d_st_dp, (size_t)s.dp_cap * sizeof(StDpItem)));
+    ST_ALLOC(ensure_dev(ctx, ctx->d_st_kc, (size_t)s.kc_cap * 8 * 2));      /* (the block list, and behind it the list of the blocks with a revision due) */ ST_ALLOC(ensure_dev(ctx, ctx->d_st_dp, (size_t)s.dp_cap * sizeof(StDpItem)));
     ST_ALLOC(ensure_dev(ctx, ctx->d_st_bincnt, (size_t)ST_NBINS * 4)); ST_ALLOC(ensure_dev(ctx, ctx->d_st_binstart, ((size_t)ST_NBINS + 1) * 4));
     ST_ALLOC(ensure_dev(ctx, ctx->d_st_dpbin, (size_t)s.dp_cap * 4)); ST_ALLOC(ensure_dev(ctx, ctx->d_st_dprank, (size_t)s.dp_cap * 4));
     ST_ALLOC(ensure_dev(ctx, ctx->d_st_sorted, (size_t)s.sorted_cap * 4)); ST_ALLOC(ensure_dev(ctx, ctx->d_st_classwave, 16 * 4));
@@ -776,7 +776,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     unsigned long long *sc = ctx->d_st_scalars;
     s.item_off = ctx->d_item_off; s.n_items = (int32_t *)(sc + 0 * 32);
     s.arena = ctx->d_st_arena; ctx->st_last_arena_cap = s.arena_cap; ctx->st_last_nsub = s.nsub;
-    s.kc_items = (long long *)ctx->d_st_kc; s.rb_items = s.kc_items + s.kc_cap; s.slow_items = s.rb_items + s.kc_cap;
+    s.kc_items = (long long *)ctx->d_st_kc; s.rb_items = s.kc_items + s.kc_cap;
     s.dp = ctx->d_st_dp;
     s.bin_count = ctx->d_st_bincnt; s.dp_bin = ctx->d_st_dpbin; s.dp_rank = ctx->d_st_dprank;
     s.bin_start = ctx->d_st_binstart; s.sorted = ctx->d_st_sorted; s.quad_cls = ctx->d_st_classwave;
@@ -882,11 +882,9 @@ static mtr_status launch_staged(mtr_ctx *ctx)
             hipLaunchKernelGGL(mtr_k_dp2_waves, dim3((unsigned)capped(waves_dp, 16)), dim3(64), 0, ctx->stream, a, s);
             HIPCHK(hipGetLastError());
         }
-        if (s.quad_min > 0) HIPCHK(hipMemsetAsync(ctx->d_st_bincnt, 0, (size_t)ST_NBINS * 4, ctx->stream));     // the revisions are sorted next
+        // (the bins' counts: mtr_k_qbins clears them behind its last read - the revisions are sorted next)
         HIPCHK(hipEventRecord(evp[4], ctx->stream));       // two-parameter alignments
         hipLaunchKernelGGL(mtr_k_select, dim3((unsigned)capped(std::min(waves, ctx->n_cu * select_wpc), 64)), dim3(64), 0, ctx->stream, a, s);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(mtr_k_select_slow, dim3((unsigned)std::min(waves, 64)), dim3(64), 0, ctx->stream, a, s);      // (blocks the kernel above left: normally none)
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(evp[5], ctx->stream));       // selection
         if (s.quad_min > 0) {
@@ -928,7 +926,6 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         HIPCHK(hipGetLastError());
         // the lists of the chain start again: everything behind the scalars that live across the passes (items, candidates, the two pass lists)
         HIPCHK(hipMemsetAsync((uint8_t *)ctx->d_st_scalars + 8 * 256, 0, st_scalar_bytes - 8 * 256, ctx->stream));
-        if (s.quad_min > 0) HIPCHK(hipMemsetAsync(ctx->d_st_bincnt, 0, (size_t)ST_NBINS * 4, ctx->stream));
         HIPCHK(hipEventRecord(ctx->ev_ph2[2], ctx->stream));
         { mtr_status ps = run_pass(1); if (ps != MTR_OK) return ps; }
     }

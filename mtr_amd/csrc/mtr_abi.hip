@@ -364,9 +364,26 @@ extern "C" void mtr_destroy(mtr_ctx *ctx)
 static mtr_status ensure_scratch(mtr_ctx *ctx, size_t bytes)
 {
     if (bytes <= ctx->scratch_bytes) return MTR_OK;
-    dfree(ctx->d_scratch); ctx->scratch_bytes = 0;
-    if (hipMalloc(&ctx->d_scratch, bytes) != hipSuccess) { ctx->err = "scratch allocation of " + std::to_string(bytes) + " bytes failed"; return MTR_ERR_OOM; }
-    ctx->scratch_bytes = bytes;
+    // [measured, round 6: BASELINE config 5 through mTR -p -g 1, 15 files of one read each] 14 batches ran on 16.2-16.5 GB of scratch per context, the 15th (the
+    // 140 kb read) asked for 16.9 GB: hipFree + hipMalloc of that buffer took 2.6 s of a 3.0 s job - memory the driver has just taken back is slow to hand out
+    // again (pick_waves, above).  So (i) a request beyond half the cap takes the whole cap (pick_waves never asks for more: the next batch of any shape fits),
+    // and (ii) the new buffer is allocated BEFORE the old one is freed, so that it does not come out of the pages just given back.
+    size_t want = bytes;
+    {
+        const char *e = getenv("MTR_SCRATCH_MAX_GB");
+        const size_t cap = (size_t)(e ? atof(e) : 16.0) << 30;
+        if (bytes > cap / 2 && bytes < cap) want = cap;
+    }
+    uint8_t *fresh = nullptr;
+    if (hipMalloc(&fresh, want) != hipSuccess) {
+        (void)hipGetLastError();
+        fresh = nullptr; want = bytes;
+        dfree(ctx->d_scratch); ctx->scratch_bytes = 0;                        // (not both at once, then: the old way)
+        if (hipMalloc(&fresh, want) != hipSuccess) { ctx->err = "scratch allocation of " + std::to_string(bytes) + " bytes failed"; return MTR_ERR_OOM; }
+    }
+    dfree(ctx->d_scratch);
+    ctx->d_scratch = fresh;
+    ctx->scratch_bytes = want;
     return MTR_OK;
 }
 

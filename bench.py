@@ -731,6 +731,8 @@ def main():
                                                                 else "HIP events around the kernel's launches in the timed region (no warm-up launch ran)"),
                         "duration_ms_in_timed_region": dom_timed_ms,
                         "cells_per_launch": dom_cells, "ops_per_cell": OPS_PER_CELL,
+                        "frac_definition": "rounds 5-6: the dominant kernel's own cells x 7 / its lone duration / VALU peak (VERDICT r4's definition); the whole-launch "
+                                           "figure that rounds 1-4 called frac is whole_launch.frac_lone_launch / frac_by_step (ADVICE r5: not comparable across that change)",
                         "cells_note": "cells (rows x unit) of the vote DPs and re-alignments the kernel ran in its passes of up to eight DPs per wavefront"}
         else:       # a batch whose chain runs one DP per wavefront (small batches) or the per-read kernel: no kernel of its own to name - the launch
             roofline = {"bound": "valu-issue", "kernel": "one launch (the chain ran one DP per wavefront: no dominant several-DPs-per-wavefront kernel)",

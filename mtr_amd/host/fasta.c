@@ -232,8 +232,9 @@ static const unsigned char *append_packed(builder *B, const unsigned char *s, co
     uint32_t *w = words_room(B, b->n_words + n / 16, wend - s) + b->n_words + n / 16;      /* the word the next base goes to */
     uint32_t pend = B->pend; int p = B->n_pend;
 #if defined(__x86_64__)
-    static int have = -1;
-    if (have < 0) have = __builtin_cpu_supports("ssse3") ? 1 : 0;
+    static int have_ssse3 = -1;                          /* (parser threads race to the same answer: relaxed atomics keep the sanitizer quiet) */
+    int have = __atomic_load_n(&have_ssse3, __ATOMIC_RELAXED);
+    if (have < 0) { have = __builtin_cpu_supports("ssse3") ? 1 : 0; __atomic_store_n(&have_ssse3, have, __ATOMIC_RELAXED); }
     if (have && wend - s >= 16) {
         if (p == 0) {                                     /* word-aligned: the blocks' words go where they belong */
             int64_t got = 0;

@@ -233,7 +233,7 @@ static void finish_batch(mtrh_run *r, mtr_ctx *ctx, mtrh_result *x)
     const double t0 = now_s();
     const mtrh_batch *b = x->batch;
     mtr_status st = r->eng.wait(ctx);
-    { static int first = 1; if (first) { first = 0; mtrh_stamp("first batch: device done"); } }
+    { static int first = 1; if (__atomic_exchange_n(&first, 0, __ATOMIC_RELAXED)) mtrh_stamp("first batch: device done"); }
     int n_report = b->n;
     if (st == MTR_ERR_DP_TOO_LARGE) {
         /* like the reference (wrap_around_DP.c:96-99): everything before the failing read is reported, then the message */

@@ -147,7 +147,7 @@ typedef struct mtrh_opts {
     int   parse_threads, print_threads;    /* 0 = default */
     const char *engine_lib;                /* NULL = default (mtrh_engine_load) */
     mtr_gather *gather;                    /* several GPUs in one process: batches leave their tables staged on the GPU for the RCCL gather (NULL: fetched to the host) */
-    int   contexts;                        /* device batches in flight per GPU: 0 = 2, or 3 where the reads are long (mean >= 8 kb: launches bound by their longest item) */
+    int   contexts;                        /* device batches in flight per GPU: 0 = 2 (3 on a long job), or 6 where the reads are long (mean >= 8 kb: launches bound by their longest item) */
 } mtrh_opts;
 typedef struct mtrh_run mtrh_run;
 /* opens the files, plans the chunks, starts the parser threads and the device thread; NULL + message on stderr on failure */

@@ -23,7 +23,7 @@
 
 typedef struct { int file; size_t begin, end; int owner, round; } chunk_t;
 /* what the device thread holds while it runs (see device_main) */
-#define MAX_CTX 3
+#define MAX_CTX 6
 typedef struct { mtr_ctx *ctxs[MAX_CTX]; mtr_file_state *fs; mtrh_result *pend[MAX_CTX]; mtr_ctx *pend_ctx[MAX_CTX]; int n_pend; int *file_ended; char *dead_msg; } device_state;
 
 struct mtrh_run {
@@ -352,8 +352,8 @@ static void device_body(mtrh_run *r, device_state *d)
 {
     /* nctx contexts = nctx device batches in flight (a context is created when a batch needs it).  Two keep the chip busy on reads of a few kb:
      * the launches are bound by instruction issue.  Launches of LONG reads (config 3's 42 kb) are bound by their longest work items - a 40 000-row
-     * alignment is one wavefront's serial chain - and leave most of the chip idle behind them: a third batch in flight fills it ([measured, MI355X]
-     * 100 reads of 42 kb per batch: 78.5 ms a step with two contexts, 53.8 with three, 51.4 with four). */
+     * alignment is one wavefront's serial chain - and leave most of the chip idle behind them: more batches in flight fill it ([measured, MI355X,
+     * round 5] 100 reads of 42 kb per batch: 78.5 ms a step with two contexts, 53.8 with three; round 6: below). */
     int fs_file = -1;
     int k = 0, dead = 0, nctx = r->o.contexts > 0 ? (r->o.contexts > MAX_CTX ? MAX_CTX : r->o.contexts) : 0;
     file_ended = (int *)calloc((size_t)r->n_files + 1, sizeof(int));
@@ -408,7 +408,10 @@ static void device_body(mtrh_run *r, device_state *d)
             if (nctx == 0) {                                     /* decided by the first batch that runs */
                 int64_t bases = 0;
                 for (int i = 0; i < b->n; i++) bases += b->lens[i];
-                nctx = bases / (b->n > 0 ? b->n : 1) >= 8000 ? 3 : 2;
+                /* round 6 [measured, MI355X, 100 reads of 42 kb per batch]: 46.6 / 38.9 / 36.4 / 32.8 / 31.6 / 34.6 ms a step with 3 / 4 / 5 / 6 / 8 / 10 batches in flight
+                 * (a lone launch is 102 ms whatever the number: tails): six for long reads - contexts come into being as batches need them, so a job of two
+                 * batches makes two, and one that cannot be created leaves the job with the ones it has */
+                nctx = bases / (b->n > 0 ? b->n : 1) >= 8000 ? 6 : 2;
                 /* a long job of short reads: a third batch in flight is worth 1.4 % ([measured] 10 000 reads of 2 kb per batch: 36.64 / 36.13 / 36.02 ms a step
                  * with two / three / four) and costs a third context's memory (16 GB) and creation (~40 ms): from ~32 batches on */
                 if (nctx == 2 && bases > 0) {

@@ -499,9 +499,9 @@ def main():
     # context, so that the next kernel is already enqueued while the host waits for the gather of the previous step.
     # --strong: ONE data set is the whole job, so a step is the whole job - kernels, then the gather, then the copy to the host, one after the other on
     # one context (repetitions of a job do not overlap each other; round 4 pipelined them and measured the next repetition's persistent kernels holding
-    # the wavefront slots the gather's kernels were waiting for: 687 ms a step for a 335 ms launch).  Config 3: three batches in flight, as the host
+    # the wavefront slots the gather's kernels were waiting for: 687 ms a step for a 335 ms launch).  Config 3: six batches in flight (round 5: three), as the host
     # pipeline runs long reads (launches bound by their longest work items leave most of the chip idle: 78.5 ms a step with two, 53.8 with three).
-    # batches in flight: three (the host pipeline's choice for long jobs and for long reads: mtr_amd/host/pipeline.c); a strong step is the whole job: one
+    # batches in flight: three (the host pipeline's choice for long jobs of short reads), six for long reads (mtr_amd/host/pipeline.c); a strong step is the whole job: one
     # (config 3: six, as the host pipeline runs long reads since round 6 - 46.6 / 38.9 / 36.4 / 32.8 / 31.6 / 34.6 ms a step with 3 / 4 / 5 / 6 / 8 / 10 in flight)
     NCTX = int(os.environ.get("MTR_BENCH_CONTEXTS", "1" if a.strong else "6" if a.config == "c3" else "3"))
     engs = [mtr_amd.Engine(device=local_rank) for _ in range(NCTX)]

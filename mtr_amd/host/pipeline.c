@@ -446,6 +446,18 @@ static void device_body(mtrh_run *r, device_state *d)
                 st = fs ? r->eng.upload_in_file(*pc, fs, b->codes, b->offs, b->lens, b->n)       /* uploads happen in file order */
                         : r->eng.upload_packed(*pc, b->packed, b->n_words, b->woff, b->lens, b->n);
                 if (st == MTR_OK) st = r->eng.run_async(*pc);
+                if (st == MTR_ERR_OOM && !fs && (k % nctx) >= 1) {
+                    /* a further context that exists but cannot get its device buffers (six contexts of long reads take 17 GB of scratch each; a card shared with
+                     * other runs): like one that cannot be created - it goes, the batches in flight are finished, and the batch runs on the first context.
+                     * (Not with -B: the file state has taken the batch's reads already.) */
+                    r->eng.destroy(*pc); *pc = NULL;
+                    finish_all(r, d);
+                    nctx = k % nctx; k = 0;
+                    pc = &ctxs[0];
+                    mtrh_stamp("a further device context ran out of memory: going on with fewer batches in flight");
+                    st = r->eng.upload_packed(*pc, b->packed, b->n_words, b->woff, b->lens, b->n);
+                    if (st == MTR_OK) st = r->eng.run_async(*pc);
+                }
                 if (st != MTR_OK) { dead = 1; dead_msg = strdup(r->eng.last_error(*pc)); }
             }
             if (!r->o.print_alignment && !r->o.file_order) { free(b->codes); b->codes = NULL; }   /* only -a rows and -B need the byte codes from here on */

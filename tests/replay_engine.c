@@ -21,6 +21,7 @@ struct mtr_ctx {
     int32_t n; int32_t *lens; uint8_t **codes; const entry **hit;
     int32_t *counts; uint8_t *blob; int64_t blob_bytes;
     int ran, fail_after;
+    int oom;                            /* MTR_REPLAY_OOM_CTX=n (tests): the n-th context created in the process (1 = the first) cannot launch: mtr_run_resident_async returns MTR_ERR_OOM */
 };
 struct mtr_file_state { int dummy; };
 
@@ -54,6 +55,7 @@ mtr_status mtr_create(int device, int manhattan, float min_match_ratio, mtr_ctx 
         c->tab[i].wire = p + 24; p += 24 + c->tab[i].wire_bytes;
     }
     c->fail_after = getenv("MTR_REPLAY_FAIL_AT") ? atoi(getenv("MTR_REPLAY_FAIL_AT")) : -1;
+    { static int created; const int nth = __atomic_add_fetch(&created, 1, __ATOMIC_RELAXED); const char *e = getenv("MTR_REPLAY_OOM_CTX"); c->oom = e && atoi(e) == nth; }
     *out = c;
     return MTR_OK;
 }
@@ -106,7 +108,13 @@ mtr_status mtr_upload_batch_in_file(mtr_ctx *c, mtr_file_state *fs, const uint8_
     for (int i = 0; i < n; i++) { c->codes[i] = (uint8_t *)malloc((size_t)lens[i] + 2); memcpy(c->codes[i], bases + offsets[i], (size_t)lens[i]); }
     return look_up(c);
 }
-mtr_status mtr_run_resident_async(mtr_ctx *c) { if (!c || c->n <= 0) return MTR_ERR_BAD_ARG; c->ran = 1; return MTR_OK; }
+mtr_status mtr_run_resident_async(mtr_ctx *c)
+{
+    if (!c || c->n <= 0) return MTR_ERR_BAD_ARG;
+    if (c->oom) { snprintf(c->err, sizeof c->err, "replayed failure: scratch allocation failed"); return MTR_ERR_OOM; }
+    c->ran = 1;
+    return MTR_OK;
+}
 
 mtr_status mtr_wait(mtr_ctx *c)
 {

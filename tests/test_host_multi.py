@@ -144,3 +144,20 @@ def test_option_errors(cli, tables):
     assert p.returncode != 0 and b"-g takes a number of GPUs" in p.stderr
     p = _run(cli, tables, ["-g", "2", "/nonexistent.fa"])
     assert p.returncode != 0 and p.stdout == b""
+
+
+@pytest.mark.parametrize("name,chunk,nth", [("synth_c4", 3000, 2), ("synth_c3", 45000, 2), ("synth_c3", 45000, 4), ("synth_c3", 45000, 6)])
+def test_a_further_context_that_runs_out_of_memory_does_not_end_the_job(cli, tables, tmp_path, name, chunk, nth):
+    """six batches in flight for long reads (pipeline.c; synth_c3: 42 kb reads, one per chunk here, the file six times over) are six contexts with their own
+    device buffers: one that is created but cannot launch (MTR_ERR_OOM: a card shared with other runs) is given up, the batches in flight are finished, and its
+    batch runs on the first context - same stdout, status 0.  The FIRST context failing that way is fatal as before."""
+    fa = tmp_path / "six_times.fa"
+    fa.write_bytes(open(gu.input_path(name), "rb").read() * 6)
+    want = _golden(name) * 6
+    p = _run(cli, tables, [str(fa)], MTR_CHUNK_BYTES=chunk, MTR_REPLAY_OOM_CTX=nth, MTR_HOST_TIMING=1)
+    assert p.returncode == 0, p.stderr.decode()[-500:]
+    assert p.stdout == want
+    assert "ran out of memory: going on with fewer" in p.stderr.decode()
+    p = _run(cli, tables, [str(fa)], MTR_CHUNK_BYTES=chunk, MTR_REPLAY_OOM_CTX=1)
+    assert p.returncode == 1 and b"replayed failure" in p.stderr
+    assert want.startswith(p.stdout)

@@ -412,6 +412,13 @@ static void device_body(mtrh_run *r, device_state *d)
                  * (a lone launch is 102 ms whatever the number: tails): six for long reads - contexts come into being as batches need them, so a job of two
                  * batches makes two, and one that cannot be created leaves the job with the ones it has */
                 nctx = bases / (b->n > 0 ? b->n : 1) >= 8000 ? 6 : 2;
+                if (nctx == 6) {
+                    /* six contexts of long reads are ~100 GB of scratch; a process that takes that much right after another gave it back waits seconds for the
+                     * driver ([measured] the same 1 200-read job 0.8 s, and 3.9 s as the second of two in a row): only where the job has the batches to earn it */
+                    int my_chunks = 0;
+                    for (int q = 0; q < r->n_chunks; q++) if (r->chunks[q].owner == r->o.rank) my_chunks++;
+                    if (my_chunks < 8) nctx = 3;
+                }
                 /* a long job of short reads: a third batch in flight is worth 1.4 % ([measured] 10 000 reads of 2 kb per batch: 36.64 / 36.13 / 36.02 ms a step
                  * with two / three / four) and costs a third context's memory (16 GB) and creation (~40 ms): from ~32 batches on */
                 if (nctx == 2 && bases > 0) {

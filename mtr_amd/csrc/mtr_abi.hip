@@ -857,7 +857,13 @@ static mtr_status launch_staged(mtr_ctx *ctx)
     // wavefronts per CU of the chain's service kernels (per block / per revision: a few dependent memory round trips per item and next to no instructions).  A
     // persistent grid holds its wavefront slots for the kernel's whole duration: sized by the chip (32 per CU) these kernels held a sixth of the step's slot time
     // for 3 % of its instructions.  MTR_SERVICE_WPC / MTR_SELECT_WPC (development) override.
-    static const int service_wpc = getenv("MTR_SERVICE_WPC") ? atoi(getenv("MTR_SERVICE_WPC")) : 32;
+    // [measured, round 6, one box, three rounds each] gather / rev_share / finish on 32 / 16 / 8 / 4 / 2 / 1 wavefronts per CU: the step 34.95 / 34.89 / 34.75 /
+    // 34.6 / 34.7 / 34.8 ms, a lone launch 44.1 / 43.7 / 43.7 / 43.5 / 44.2 / 45.4 ms - their items are three contended atomics and a store fence each, and a
+    // quarter of the wavefronts contend less; so four per CU for a batch of the headline's size, growing with the batch (a wavefront per 20 000 bases) up to the
+    // 32 per CU that the 100 000-read batches had.  (The selection and the polish kernel on fewer wavefronts: nothing, or slower.)
+    static const int service_wpc_env = getenv("MTR_SERVICE_WPC") ? atoi(getenv("MTR_SERVICE_WPC")) : 0;
+    const int service_waves = service_wpc_env > 0 ? ctx->n_cu * service_wpc_env
+                                                  : (int)std::min<int64_t>((int64_t)ctx->n_cu * 32, std::max<int64_t>((int64_t)ctx->n_cu * 4, sumL / 20000));
     static const int select_wpc = getenv("MTR_SELECT_WPC") ? atoi(getenv("MTR_SELECT_WPC")) : 16;
     static const int polish_wpc = getenv("MTR_POLISH_WPC") ? atoi(getenv("MTR_POLISH_WPC")) : 16;
     hipLaunchKernelGGL(mtr_k_items, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t *)ctx->d_rcount, s);
@@ -881,7 +887,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(mtr_k_walks_k, dim3((unsigned)capped(ww, 32)), dim3(64), 0, ctx->stream, aw, s);
             HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL(mtr_k_gather, dim3((unsigned)capped(ctx->n_cu * service_wpc, 64)), dim3(64), 0, ctx->stream, a, s);      // (19 VGPRs, no LDS: eight wavefronts per SIMD hide its loads)
+            hipLaunchKernelGGL(mtr_k_gather, dim3((unsigned)capped(service_waves, 64)), dim3(64), 0, ctx->stream, a, s);      // (19 VGPRs, no LDS: eight wavefronts per SIMD hide its loads)
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(evp[3], ctx->stream));       // unit search (tables, seeds, walks) + the alignment items
@@ -918,7 +924,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
                 hipLaunchKernelGGL(mtr_k_polish, dim3((unsigned)capped(std::min(wp, ctx->n_cu * polish_wpc), 256)), dim3(64), 0, ctx->stream, ap, s);
                 HIPCHK(hipGetLastError());
             }
-            hipLaunchKernelGGL(mtr_k_rev_share, dim3((unsigned)capped(ctx->n_cu * service_wpc, 64)), dim3(64), 0, ctx->stream, a, s);
+            hipLaunchKernelGGL(mtr_k_rev_share, dim3((unsigned)capped(service_waves, 64)), dim3(64), 0, ctx->stream, a, s);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(mtr_k_qbins, dim3(1), dim3(1024), 0, ctx->stream, s, 1);
             HIPCHK(hipGetLastError());
@@ -933,7 +939,7 @@ static mtr_status launch_staged(mtr_ctx *ctx)
         } else hipLaunchKernelGGL(mtr_k_revise, dim3((unsigned)capped(waves, 64)), dim3(64), 0, ctx->stream, a, s);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(evp[6], ctx->stream));       // revisions
-        hipLaunchKernelGGL(mtr_k_finish, dim3((unsigned)capped(ctx->n_cu * service_wpc, 64)), dim3(64), 0, ctx->stream, a, s);
+        hipLaunchKernelGGL(mtr_k_finish, dim3((unsigned)capped(service_waves, 64)), dim3(64), 0, ctx->stream, a, s);
         HIPCHK(hipGetLastError());
         return MTR_OK;
     };

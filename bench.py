@@ -247,8 +247,15 @@ def launcher_rate(reads, n_total, n_gpus, force_rccl=False):
             if best is None or dt < best:
                 best = dt
                 gather = [ln for ln in p.stderr.decode(errors="replace").splitlines() if "\tgather " in ln]
-    return {"command": f"mTR -c -g {n_gpus} <fasta of {n_total} reads> > /dev/null", "reads": n_total, "gpus": n_gpus, "seconds": best, "reads_per_s": n_total / best,
-            "gather": gather[0] if gather else None}
+    out = {"command": f"mTR -c -g {n_gpus} <fasta of {n_total} reads> > /dev/null" + (" with MTR_GATHER=rccl" if force_rccl else ""), "reads": n_total, "gpus": n_gpus,
+           "seconds": best, "reads_per_s": n_total / best, "gather": gather[0] if gather else None}
+    if gather and "gather rccl, " in gather[0]:
+        try:
+            out["exchanges_over_rccl"] = int(gather[0].split("gather rccl, ")[1].split(" exchange")[0])
+            out["exchanges_straight_to_the_host"] = int(gather[0].split(" over RCCL + ")[1].split(" straight")[0])
+        except Exception:
+            pass
+    return out
 
 
 C5_FILES = ["3_5", "3_10", "3_20", "3_50", "5_10", "5_20", "5_50", "10_20", "10_50", "20_50", "2_5_10_20_set", "2_5_10_20_50_100_200_set",
